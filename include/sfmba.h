@@ -1,0 +1,172 @@
+/*
+ * sfmba.h - C ABI of libsfmba.so, the MI355X (gfx950) bundle-adjustment engine.
+ *
+ * The library replaces the arithmetic behind BundleAdjustment.optimize() of the reference
+ * (/root/reference/bundle_adjustment.py:128-150): the residual function fun()
+ * (bundle_adjustment.py:34-50, cv2.Rodrigues + cv2.projectPoints per observation), the
+ * finite-differenced sparse Jacobian requested through jac_sparsity (bundle_adjustment.py:53-74,
+ * 139) and scipy.optimize.least_squares(method='trf') (bundle_adjustment.py:141-143).
+ *
+ * All arrays are plain host pointers in the reference's own layout (the five arrays of
+ * optimize_data.npz, bundle_adjustment.py:125-126).  Nothing is retained after a call returns.
+ * Every function returns 0 on success and a negative sfmba_error otherwise; the message of the
+ * most recent failure on a handle is available from sfmba_last_error().  No function throws or
+ * aborts across this boundary.  A handle is not re-entrant; distinct handles are independent.
+ */
+#ifndef SFMBA_H
+#define SFMBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfmba_handle sfmba_handle;
+
+enum sfmba_error {
+    SFMBA_OK = 0,
+    SFMBA_ERR_INVALID_ARGUMENT = -1, /* null pointer, negative size, no problem set */
+    SFMBA_ERR_INDEX_RANGE = -2,      /* camera/point index outside [0,n): NumPy IndexError at bundle_adjustment.py:49 */
+    SFMBA_ERR_NONFINITE = -3,        /* non-finite initial residuals: SciPy ValueError, least_squares.py:844-845 */
+    SFMBA_ERR_HIP = -4,              /* a HIP runtime call failed */
+    SFMBA_ERR_COMM = -5,             /* RCCL missing or a collective failed */
+    SFMBA_ERR_NO_DEVICE = -6         /* no usable gfx950 device */
+};
+
+/* Termination codes: the ones scipy.optimize.least_squares reports
+ * (scipy/optimize/_lsq/least_squares.py:18-25). */
+enum sfmba_status {
+    SFMBA_STATUS_MAX_NFEV = 0,
+    SFMBA_STATUS_GTOL = 1,
+    SFMBA_STATUS_FTOL = 2,
+    SFMBA_STATUS_XTOL = 3,
+    SFMBA_STATUS_FTOL_XTOL = 4
+};
+
+enum sfmba_linear_solver {
+    SFMBA_SOLVER_AUTO = 0, /* dense Cholesky when 6*n_cameras <= dense_max_dim, else PCG */
+    SFMBA_SOLVER_PCG = 1,  /* block-Jacobi preconditioned CG on the implicit Schur complement */
+    SFMBA_SOLVER_DENSE = 2 /* explicit Schur complement + fp64 MFMA blocked Cholesky */
+};
+
+typedef struct sfmba_options {
+    /* Same meaning and defaults as the reference's least_squares call
+     * (bundle_adjustment.py:141: ftol=1e-4, xtol=1e-12; SciPy default gtol=1e-8,
+     * max_nfev = 100*n when 0). */
+    double ftol;
+    double xtol;
+    double gtol;
+    int32_t max_nfev;
+    /* Levenberg-Marquardt / linear solver controls (no counterpart in the reference). */
+    int32_t max_iterations;   /* cap on LM iterations (accepted + rejected); 0 = 200 */
+    double initial_lambda;    /* initial damping; 0 = 1e-4 */
+    double pcg_rtol;          /* PCG stops at sqrt(r'M^-1 r / r0'M^-1 r0) <= pcg_rtol; 0 = 0.1 */
+    int32_t pcg_max_iter;     /* 0 = 1000 */
+    int32_t linear_solver;    /* enum sfmba_linear_solver */
+    int32_t dense_max_dim;    /* 0 = 1536 */
+    int32_t verbose;          /* 2 prints one line per LM iteration (SciPy verbose=2 columns) */
+    int32_t profile;          /* 1 brackets every kernel family with HIP events (fills sfmba_stats.ms_*) */
+    int32_t device;           /* HIP device ordinal, -1 = current device */
+    /* Point partition of this handle: it owns the rank-th of nranks contiguous point ranges
+     * (equal observation counts).  nranks <= 1 means the whole problem. */
+    int32_t rank;
+    int32_t nranks;
+} sfmba_options;
+
+typedef struct sfmba_stats {
+    int32_t status;           /* enum sfmba_status */
+    int32_t iterations;       /* LM iterations, accepted + rejected */
+    int32_t accepted;         /* accepted steps */
+    int32_t nfev;             /* cost evaluations (initial + one per trial step) */
+    int32_t njev;             /* linearisations */
+    int32_t pcg_iterations;   /* total PCG iterations (0 for the dense solver) */
+    int32_t linear_solver;    /* solver actually used */
+    int32_t reserved;
+    double initial_cost;      /* 0.5*||f||^2, SciPy's convention */
+    double final_cost;
+    double optimality;        /* inf-norm of the gradient at the final iterate */
+    double solve_seconds;     /* wall time of sfmba_solve */
+    /* GPU time per kernel family inside sfmba_solve, HIP-event measured, milliseconds, and
+     * the number of launches of each. */
+    double ms_linearize;  int64_t n_linearize;
+    double ms_damp;       int64_t n_damp;
+    double ms_spmv_pm;    int64_t n_spmv_pm;   /* point-major half of the Schur matvec */
+    double ms_spmv_cm;    int64_t n_spmv_cm;   /* camera-major half of the Schur matvec */
+    double ms_pcg_vec;    int64_t n_pcg_vec;   /* camera-vector kernels of PCG */
+    double ms_back;       int64_t n_back;
+    double ms_cost;       int64_t n_cost;
+    double ms_dense;      int64_t n_dense;     /* dense Schur assembly + Cholesky + solves */
+} sfmba_stats;
+
+/* Fill *opts with the defaults listed above. */
+void sfmba_default_options(sfmba_options* opts);
+
+/* Create / destroy an engine instance bound to one GPU. */
+int sfmba_create(const sfmba_options* opts, sfmba_handle** out);
+int sfmba_destroy(sfmba_handle* h);
+const char* sfmba_last_error(const sfmba_handle* h);
+
+/* Load one problem: the arrays BundleAdjustment.view2idx() produces
+ * (bundle_adjustment.py:94-126) plus the 3x3 intrinsic matrix (row-major; only K[0][0],
+ * K[1][1], K[0][2], K[1][2] are used, as cv2.projectPoints does with empty distortion).
+ * camera_params is n_cameras x 12 (row-major 3x3 rotation block, then translation); the 3x3
+ * block is replaced by its polar orthogonal factor exactly as cv2.Rodrigues does at
+ * bundle_adjustment.py:24.  Observations may come in any order. */
+int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
+                      const double* camera_params, const double* points_3d,
+                      const int64_t* camera_indices, const int64_t* point_indices,
+                      const double* points_2d, const double* K);
+
+/* Overwrite the current parameter estimate without re-sending the observations (used to
+ * re-run a solve from the same start, and to evaluate fun() at another x). */
+int sfmba_set_params(sfmba_handle* h, const double* camera_params, const double* points_3d);
+
+/* fun(params) of bundle_adjustment.py:34-50 at the current estimate: out has 2*n_obs entries,
+ * [du0, dv0, du1, dv1, ...] in the caller's observation order.  On a partitioned handle only
+ * the entries of locally owned observations are written (the rest are left untouched). */
+int sfmba_residuals(sfmba_handle* h, double* out);
+
+/* Analytic Jacobian blocks at the current estimate, caller's observation order:
+ * jac_cam is n_obs x 2 x 6 with columns (dw0, dw1, dw2, dt0, dt1, dt2) of the left
+ * perturbation Y' = exp([dw]x) Y + dt of the camera-frame point Y = R X + t;
+ * jac_pt is n_obs x 2 x 3 (d residual / d X).  They take the place of the 2-point finite
+ * differences SciPy forms through jac_sparsity (bundle_adjustment.py:139-141). */
+int sfmba_jacobian_blocks(sfmba_handle* h, double* jac_cam, double* jac_pt);
+
+/* Run the Levenberg-Marquardt solve from the current estimate: the replacement for the
+ * least_squares call at bundle_adjustment.py:141-143. */
+int sfmba_solve(sfmba_handle* h, sfmba_stats* stats);
+
+/* Current estimate in the reference's output layout (bundle_adjustment.py:147-150):
+ * poses n_cameras x 12 (orthonormal rotation block + translation), points n_points x 3. */
+int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d);
+
+/* ---- diagnostics used by the parity tests: one linearisation at the current estimate ---- */
+
+/* Linearise and damp with lambda.  Afterwards the blocks below can be read. */
+int sfmba_linearize(sfmba_handle* h, double lambda);
+/* U: n_cameras x 36 (J_c'J_c per camera), g_cam: n_cameras x 6, V: n_points x 9 (J_p'J_p per
+ * point, owned points only on a partitioned handle), g_pt: n_points x 3.  Any may be NULL. */
+int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, double* g_pt);
+/* y = S x with S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p', x and y n_cameras x 6. */
+int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y);
+/* Reduced right-hand side b = -g_cam + sum W V*^-1 g_pt and inverse of the block-Jacobi
+ * preconditioner blocks (n_cameras x 36).  Either may be NULL. */
+int sfmba_get_reduced(sfmba_handle* h, double* rhs, double* precond_inv);
+/* Solve the damped normal equations for the step at the current linearisation:
+ * step_cam n_cameras x 6, step_pt n_points x 3; *pcg_iters receives the iteration count. */
+int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t* pcg_iters);
+
+/* ---- multi-GPU: one handle (one process) per GPU, RCCL over xGMI ---- */
+
+/* Rank 0 obtains a 128-byte RCCL unique id and distributes it (torch.distributed broadcast);
+ * every rank then joins.  After sfmba_comm_init the camera-block partial sums, the reduced
+ * matvec partials and the cost partials of each iteration are all-reduced across ranks. */
+int sfmba_comm_unique_id(void* out128);
+int sfmba_comm_init(sfmba_handle* h, const void* unique_id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMBA_H */

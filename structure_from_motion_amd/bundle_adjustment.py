@@ -1,0 +1,198 @@
+"""Drop-in for the reference's ``bundle_adjustment`` module on one MI355X.
+
+Same names, arguments, return values and side effects as
+/root/reference/bundle_adjustment.py: ``project`` (:10), ``fun`` (:34),
+``bundle_adjustment_sparsity`` (:53) and ``BundleAdjustment`` (:77) with ``view2idx`` (:94)
+and ``optimize`` (:128).  The arithmetic runs in libsfmba.so (HIP kernels for gfx950, see
+include/sfmba.h): ``fun``/``project`` evaluate the reprojection on the GPU and ``optimize``
+replaces ``scipy.optimize.least_squares(method='trf')`` over a finite-differenced Jacobian
+(:141-143) by a Levenberg-Marquardt / Schur-complement solve with analytic Jacobians.
+There is no CPU fallback: without the shared library or without a GPU these functions raise.
+"""
+from __future__ import annotations
+
+import logging
+import time
+
+import numpy as np
+from scipy.sparse import lil_matrix
+
+from .engine import Engine, TERMINATION_MESSAGES
+
+__all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment"]
+
+_ZERO_2D = {}
+_fun_cache = {"key": None, "engine": None, "keep": None}
+
+
+def project(points, camera_params, K, dist=np.array([])):
+    """
+    Project 3D points with the given camera parameters (R matrix and t vector) and intrinsic
+    matrix (reference: bundle_adjustment.py:10-31).  ``points`` (N x 3) and ``camera_params``
+    (N x 12, [:9] rotation matrix entries, [9:12] translation) are per observation; ``dist``
+    is ignored exactly as the reference's empty distortion is.  Returns N x 2.
+    """
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    camera_params = np.ascontiguousarray(camera_params, dtype=np.float64).reshape(-1, 12)
+    n = camera_params.shape[0]
+    if points.shape[0] != n:
+        raise IndexError(f"index {min(points.shape[0], n)} is out of bounds for axis 0 with size "
+                         f"{min(points.shape[0], n)}")
+    if n == 0:
+        return np.zeros((0,))
+    idx = np.arange(n, dtype=np.int64)
+    with Engine() as eng:
+        eng.set_problem(camera_params, points, idx, idx, np.zeros((n, 2)), K)
+        return eng.residuals().reshape(n, 2)
+
+
+def _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d, K):
+    ci = np.asarray(camera_indices)
+    pi = np.asarray(point_indices)
+    uv = np.asarray(points_2d)
+    Ka = np.asarray(K, dtype=np.float64)
+    key = (n_cameras, n_points, ci.__array_interface__["data"][0], ci.size,
+           pi.__array_interface__["data"][0], uv.__array_interface__["data"][0], Ka.tobytes())
+    if _fun_cache["key"] != key:
+        if _fun_cache["engine"] is not None:
+            _fun_cache["engine"].close()
+        _fun_cache.update(key=None, engine=None, keep=None)
+        eng = Engine()
+        eng.set_problem(np.tile(np.r_[np.eye(3).ravel(), 0, 0, 1.0], (n_cameras, 1)),
+                        np.zeros((n_points, 3)), ci, pi, uv, Ka)
+        _fun_cache.update(key=key, engine=eng, keep=(ci, pi, uv))   # keep the arrays alive
+    return _fun_cache["engine"]
+
+
+def fun(params, n_cameras, n_points, camera_indices, point_indices, points_2d, K):
+    """
+    Reprojection residuals (reference: bundle_adjustment.py:34-50): ``params`` is
+    [camera parameters (n_cameras*12); 3D points (n_points*3)]; returns
+    ``(projected - points_2d).ravel()`` of length 2*n_obs, evaluated on the GPU.
+    """
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    camera_params = params[:n_cameras * 12].reshape((n_cameras, 12))
+    points_3d = params[n_cameras * 12:].reshape((n_points, 3))
+    eng = _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
+    eng.set_params(camera_params, points_3d)
+    return eng.residuals()
+
+
+def bundle_adjustment_sparsity(n_cameras, n_points, camera_indices, point_indices):
+    """
+    Jacobian sparsity pattern (reference: bundle_adjustment.py:53-74): a ``lil_matrix`` of
+    shape (2*n_obs, 12*n_cameras + 3*n_points) with 12 camera and 3 point columns set in both
+    rows of every observation.  The engine does not need it (its block structure is
+    implicit); it is produced for callers that still hand it to SciPy.
+    """
+    camera_indices = np.asarray(camera_indices)
+    point_indices = np.asarray(point_indices)
+    m = camera_indices.size * 2
+    n = n_cameras * 12 + n_points * 3
+    A = lil_matrix((m, n), dtype=int)
+    i = np.arange(camera_indices.size)
+    for s in range(12):
+        A[2 * i, camera_indices * 12 + s] = 1
+        A[2 * i + 1, camera_indices * 12 + s] = 1
+    for s in range(3):
+        A[2 * i, n_cameras * 12 + point_indices * 3 + s] = 1
+        A[2 * i + 1, n_cameras * 12 + point_indices * 3 + s] = 1
+    return A
+
+
+class BundleAdjustment:
+    """Reference: bundle_adjustment.py:77-150.  Same constructor, attributes and results."""
+
+    def __init__(self, wpSet, K, dist, completed_views, ftol=1e-4, xtol=1e-12, gtol=1e-8,
+                 max_nfev=None, verbose=2, **engine_options):
+        self.completed_views = completed_views
+        self.wpSet = wpSet
+        self.points_3d = wpSet.world_points
+        self.points_2d = []
+        self.point_indices = []
+        self.camera_indices = []
+        self.view_idx = {}
+        self.camera_params = []
+        self.focal_len = (K[0, 0] + K[1, 1]) / 2
+        self.dist = dist[0][:2]
+        self.K = K
+        self.correspondences = wpSet.correspondences
+        self.n_cameras = None
+        self.n_points = None
+        # solver settings: the literals of bundle_adjustment.py:141 unless overridden
+        self.ftol, self.xtol, self.gtol = ftol, xtol, gtol
+        self.max_nfev, self.verbose = max_nfev, verbose
+        self.engine_options = engine_options
+        self.result = None
+
+    def view2idx(self):
+        """
+        Takes in a list of views and converts them to indices.  For each 2D point a view index
+        is assigned (reference: bundle_adjustment.py:94-126, without the per-row Python loop).
+        """
+        for view in self.completed_views:
+            if view.id not in self.view_idx:
+                self.view_idx[view.id] = len(self.view_idx)
+            rot_vec = np.squeeze(view.rotation)
+            params = np.concatenate((rot_vec, view.translation.reshape((1, 3))), axis=None).tolist()
+            self.camera_params.append(params)
+        self.camera_params = np.array(self.camera_params)
+
+        corr = self.correspondences
+        n_rows = len(corr)
+        if n_rows:
+            view_ids = np.array(corr["ViewId"].tolist(), dtype=object).reshape(n_rows, -1)[:, :2]
+            lookup = self.view_idx
+            self.camera_indices = np.array([lookup[v] for v in view_ids.ravel()], dtype=np.int64)
+            self.points_2d = np.array([np.asarray(f[:2], dtype=np.float64)
+                                       for f in corr["FeatureIndex"]]).reshape(2 * n_rows, -1)
+            self.point_indices = np.repeat(np.asarray(corr.index), 2)
+        else:
+            self.camera_indices = np.array([])
+            self.point_indices = np.array([])
+            self.points_2d = np.array([])
+        self.points_3d = np.array(self.points_3d)
+        self.n_points = self.points_3d.shape[0]
+        self.n_cameras = self.camera_params.shape[0]
+        logging.info(f"Number of views processed: {self.n_cameras}.")
+        logging.info(f"Number of 3D points processed: {self.n_points}.")
+        np.savez('optimize_data', camera_params=self.camera_params, points_3d=self.points_3d,
+                 camera_indices=self.camera_indices, point_indices=self.point_indices, points_2d=self.points_2d)
+
+    def optimize(self):
+        """
+        Performs optimization on the reprojection error by updating poses and 3D points.
+        :return poses: (N x 12) array, [:9] rotation matrix entries, [9:12] translation
+        :return points_3d: optimized 3D points
+        """
+        self.view2idx()
+        print(len(self.camera_params.ravel()), len(self.points_3d.ravel()))
+        opts = dict(ftol=self.ftol, xtol=self.xtol, gtol=self.gtol, verbose=int(self.verbose))
+        if self.max_nfev:
+            opts["max_nfev"] = int(self.max_nfev)
+        opts.update(self.engine_options)
+        with Engine(**opts) as eng:
+            eng.set_problem(self.camera_params, self.points_3d, self.camera_indices,
+                            self.point_indices, self.points_2d, self.K)
+            t0 = time.time()
+            stats = eng.solve()
+            t1 = time.time()
+            poses, points_3d = eng.get_params()
+        logging.info(f"Optimized {self.n_points} in {t1-t0} seconds.")
+        self.result = stats.as_dict()
+        self.result["message"] = TERMINATION_MESSAGES[stats.status]
+        self.result["success"] = stats.status > 0
+        return poses, points_3d
+
+
+def solve_arrays(camera_params, points_3d, camera_indices, point_indices, points_2d, K, **options):
+    """Array-level entry point: the five arrays of ``optimize_data.npz``
+    (bundle_adjustment.py:125-126) in, ``(poses, points_3d, stats dict)`` out."""
+    with Engine(**options) as eng:
+        eng.set_problem(camera_params, points_3d, camera_indices, point_indices, points_2d, K)
+        stats = eng.solve()
+        poses, pts = eng.get_params()
+    out = stats.as_dict()
+    out["message"] = TERMINATION_MESSAGES[stats.status]
+    out["success"] = stats.status > 0
+    return poses, pts, out

@@ -1,0 +1,251 @@
+// Device-side building blocks shared by every kernel of libsfmba: the projection model of
+// /root/reference/bundle_adjustment.py:10-31 (cv2.projectPoints with a fixed K and no
+// distortion), its analytic derivatives, tiny dense factorizations held in registers, and
+// wave/block reductions for 64-lane wavefronts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfmba {
+
+struct Intr { double fx, fy, cx, cy; };
+
+// One camera as stored in HBM: 12 doubles = row-major rotation Q (9) then translation t (3),
+// 96 bytes, 16-byte aligned, so a gather is six 16-byte loads.
+struct Cam { double q[9]; double t[3]; };
+
+__device__ __forceinline__ Cam load_cam(const double2* __restrict__ cams, int c) {
+    const double2* p = cams + 6 * (size_t)c;
+    double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5];
+    Cam k;
+    k.q[0] = a0.x; k.q[1] = a0.y; k.q[2] = a1.x; k.q[3] = a1.y; k.q[4] = a2.x; k.q[5] = a2.y;
+    k.q[6] = a3.x; k.q[7] = a3.y; k.q[8] = a4.x; k.t[0] = a4.y; k.t[1] = a5.x; k.t[2] = a5.y;
+    return k;
+}
+
+// Normalised image coordinates of a point in a camera: x = Y0/Z, y = Y1/Z, iz = 1/Z with the
+// cv2.projectPoints guard (Z == 0 is treated as Z == 1).
+struct Seed { double x, y, iz; };
+
+__device__ __forceinline__ Seed project_seed(const Cam& k, double X0, double X1, double X2) {
+    double Y0 = k.q[0] * X0 + k.q[1] * X1 + k.q[2] * X2 + k.t[0];
+    double Y1 = k.q[3] * X0 + k.q[4] * X1 + k.q[5] * X2 + k.t[1];
+    double Y2 = k.q[6] * X0 + k.q[7] * X1 + k.q[8] * X2 + k.t[2];
+    Seed s;
+    s.iz = (Y2 != 0.0) ? 1.0 / Y2 : 1.0;
+    s.x = Y0 * s.iz;
+    s.y = Y1 * s.iz;
+    return s;
+}
+
+// Residual (reprojection minus observation), bundle_adjustment.py:50.
+__device__ __forceinline__ void residual(const Seed& s, const Intr& K, double u, double v,
+                                         double& ru, double& rv) {
+    ru = (K.fx * s.x + K.cx) - u;
+    rv = (K.fy * s.y + K.cy) - v;
+}
+
+// d residual / d (dw, dt) for the left perturbation Y' = exp([dw]x) Y + dt.  Depends on the
+// seed only.  jc[0..5] is the u row, jc[6..11] the v row.
+__device__ __forceinline__ void jac_cam(const Seed& s, const Intr& K, double* jc) {
+    const double fx = K.fx, fy = K.fy;
+    jc[0] = -fx * s.x * s.y;
+    jc[1] = fx * (1.0 + s.x * s.x);
+    jc[2] = -fx * s.y;
+    jc[3] = fx * s.iz;
+    jc[4] = 0.0;
+    jc[5] = -fx * s.x * s.iz;
+    jc[6] = -fy * (1.0 + s.y * s.y);
+    jc[7] = fy * s.x * s.y;
+    jc[8] = fy * s.x;
+    jc[9] = 0.0;
+    jc[10] = fy * s.iz;
+    jc[11] = -fy * s.y * s.iz;
+}
+
+// d residual / d X: rows a (u) and b (v).
+__device__ __forceinline__ void jac_pt(const Seed& s, const Intr& K, const double* q,
+                                       double* a, double* b) {
+    const double fu = K.fx * s.iz, fv = K.fy * s.iz;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a[k] = fu * (q[k] - s.x * q[6 + k]);
+        b[k] = fv * (q[3 + k] - s.y * q[6 + k]);
+    }
+}
+
+// w = Jc * d for a camera tangent d (6): two numbers.
+__device__ __forceinline__ void jc_times(const Seed& s, const Intr& K, const double* d,
+                                         double& w0, double& w1) {
+    // v = dw x (x, y, 1) + dt * iz ; w0 = fx (v0 - x v2), w1 = fy (v1 - y v2)
+    double v0 = d[1] - d[2] * s.y + d[3] * s.iz;
+    double v1 = d[2] * s.x - d[0] + d[4] * s.iz;
+    double v2 = d[0] * s.y - d[1] * s.x + d[5] * s.iz;
+    w0 = K.fx * (v0 - s.x * v2);
+    w1 = K.fy * (v1 - s.y * v2);
+}
+
+// out(3) += Jp^T * (w0, w1) = Q^T e with e = (fu w0, fv w1, -(x fu w0 + y fv w1)).
+__device__ __forceinline__ void jpT_times_acc(const Seed& s, const Intr& K, const double* q,
+                                              double w0, double w1, double* out) {
+    const double e0 = K.fx * s.iz * w0, e1 = K.fy * s.iz * w1;
+    const double e2 = -(s.x * e0 + s.y * e1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] += q[k] * e0 + q[3 + k] * e1 + q[6 + k] * e2;
+}
+
+// (w0, w1) = Jp * d for a point step d (3).
+__device__ __forceinline__ void jp_times(const Seed& s, const Intr& K, const double* q,
+                                         const double* d, double& w0, double& w1) {
+    const double y0 = q[0] * d[0] + q[1] * d[1] + q[2] * d[2];
+    const double y1 = q[3] * d[0] + q[4] * d[1] + q[5] * d[2];
+    const double y2 = q[6] * d[0] + q[7] * d[1] + q[8] * d[2];
+    w0 = K.fx * s.iz * (y0 - s.x * y2);
+    w1 = K.fy * s.iz * (y1 - s.y * y2);
+}
+
+// out(6) += Jc^T * (w0, w1).
+__device__ __forceinline__ void jcT_times_acc(const Seed& s, const Intr& K, double w0, double w1,
+                                              double* out) {
+    const double a = K.fx * w0, b = K.fy * w1;
+    out[0] += -a * s.x * s.y - b * (1.0 + s.y * s.y);
+    out[1] += a * (1.0 + s.x * s.x) + b * s.x * s.y;
+    out[2] += -a * s.y + b * s.x;
+    out[3] += a * s.iz;
+    out[4] += b * s.iz;
+    out[5] += -(a * s.x + b * s.y) * s.iz;
+}
+
+// Packed upper triangle of a symmetric N x N matrix, row-major: (i, j), i <= j.
+__host__ __device__ constexpr int upidx(int n, int i, int j) { return i * n - (i * (i - 1)) / 2 + (j - i); }
+
+// Inverse of a symmetric positive definite 3x3 given as packed upper (00 01 02 11 12 22).
+__device__ __forceinline__ void spd3_inverse(const double* a, double* inv) {
+    const double tiny = 1e-300;
+    double l00 = sqrt(fmax(a[0], tiny));
+    double i00 = 1.0 / l00;
+    double l10 = a[1] * i00, l20 = a[2] * i00;
+    double l11 = sqrt(fmax(a[3] - l10 * l10, tiny));
+    double i11 = 1.0 / l11;
+    double l21 = (a[4] - l20 * l10) * i11;
+    double l22 = sqrt(fmax(a[5] - l20 * l20 - l21 * l21, tiny));
+    double i22 = 1.0 / l22;
+    double i10 = -l10 * i00 * i11;
+    double i21 = -l21 * i11 * i22;
+    double i20 = -(l20 * i00 + l21 * i10) * i22;
+    inv[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    inv[1] = i10 * i11 + i20 * i21;
+    inv[2] = i20 * i22;
+    inv[3] = i11 * i11 + i21 * i21;
+    inv[4] = i21 * i22;
+    inv[5] = i22 * i22;
+}
+
+// In-register Cholesky inverse of a symmetric positive definite 6x6 (full storage, row-major).
+// Returns false when a pivot is not positive; A is destroyed, Ainv receives the full inverse.
+__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+        if (!(d > 0.0)) { ok = false; d = 1.0; }
+        double l = sqrt(d), il = 1.0 / l;
+        A[j][j] = l;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
+            A[i][j] = v * il;
+        }
+    }
+    // Linv (lower) by forward substitution, stored in the lower triangle of Ainv.
+    double Li[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        Li[j][j] = 1.0 / A[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) v -= A[i][k] * Li[k][j];
+            Li[i][j] = v / A[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = j; k < 6; ++k) v += Li[k][i] * Li[k][j];
+            Ainv[i][j] = v;
+            Ainv[j][i] = v;
+        }
+    return ok;
+}
+
+// exp([w]x) as a row-major 3x3.
+__device__ __forceinline__ void so3_exp(const double* w, double* E) {
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double a, b;
+    if (t2 < 1e-8) {
+        a = 1.0 - t2 / 6.0;
+        b = 0.5 - t2 / 24.0;
+    } else {
+        const double t = sqrt(t2);
+        a = sin(t) / t;
+        b = (1.0 - cos(t)) / t2;
+    }
+    // K = [w]x ; K^2 = w w^T - t2 I
+    E[0] = 1.0 + b * (w[0] * w[0] - t2);
+    E[1] = -a * w[2] + b * w[0] * w[1];
+    E[2] = a * w[1] + b * w[0] * w[2];
+    E[3] = a * w[2] + b * w[0] * w[1];
+    E[4] = 1.0 + b * (w[1] * w[1] - t2);
+    E[5] = -a * w[0] + b * w[1] * w[2];
+    E[6] = -a * w[1] + b * w[0] * w[2];
+    E[7] = a * w[0] + b * w[1] * w[2];
+    E[8] = 1.0 + b * (w[2] * w[2] - t2);
+}
+
+// ---- reductions over a 64-lane wavefront / a workgroup ---------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Sum over the workgroup (blockDim.x a multiple of 64, at most 1024); the result is valid in
+// thread 0.  scratch must hold 16 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r = fmax(r, scratch[i]);
+    return r;
+}
+
+}  // namespace sfmba

@@ -1,0 +1,918 @@
+// Host side of libsfmba: problem packing (polar projection of the rotation blocks, point-major
+// and camera-major orderings, chunking, partitioning over ranks), the Levenberg-Marquardt loop
+// that takes the place of scipy.optimize.least_squares(method='trf')
+// (/root/reference/bundle_adjustment.py:141-143; scipy/optimize/_lsq/trf.py:401-560), and the
+// C ABI declared in include/sfmba.h.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/sfmba.h"
+#include "sfmba_internal.h"
+
+using namespace sfmba;
+
+namespace {
+
+// ---------------------------------------------------------------------------------- errors
+struct HipError { hipError_t e; const char* what; };
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) throw HipError{e_, #expr};           \
+    } while (0)
+
+struct ApiError { int code; std::string msg; };
+
+[[noreturn]] void fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw ApiError{code, buf};
+}
+
+// ---------------------------------------------------------------------------------- RCCL
+// Resolved at run time so that a single-GPU process never needs the library.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);   // reuse a copy the process already holds
+        for (int i = 0; !lib && i < 3; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+            err = "librccl lacks a required symbol";
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+// ---------------------------------------------------------------------------------- polar
+// Orthogonal polar factor U V' of a 3x3 (what cv2.Rodrigues keeps of its input,
+// /root/reference/bundle_adjustment.py:24) by one-sided Jacobi SVD, then the cv2 rule that a
+// rotation with sin(angle) < 1e-5 and cos(angle) > 0 is the identity.
+void polar3(const double* R, double* Q) {
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = R[3 * i + j];
+    const double eps = std::numeric_limits<double>::epsilon();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int i = 0; i < 3; ++i) { al += A[i][p] * A[i][p]; be += A[i][q] * A[i][q]; ga += A[i][p] * A[i][q]; }
+                if (std::fabs(ga) <= eps * std::sqrt(al * be) || ga == 0.0) continue;
+                rotated = true;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    double a = A[i][p], b = A[i][q];
+                    A[i][p] = c * a - s * b; A[i][q] = s * a + c * b;
+                    a = V[i][p]; b = V[i][q];
+                    V[i][p] = c * a - s * b; V[i][q] = s * a + c * b;
+                }
+            }
+        if (!rotated) break;
+    }
+    double U[3][3], sig[3];
+    for (int j = 0; j < 3; ++j) {
+        sig[j] = std::sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    }
+    const double smax = std::max(sig[0], std::max(sig[1], sig[2]));
+    bool good[3];
+    int ngood = 0;
+    for (int j = 0; j < 3; ++j) {
+        good[j] = sig[j] > 1e-14 * smax && sig[j] > 0.0;
+        if (good[j]) { ++ngood; for (int i = 0; i < 3; ++i) U[i][j] = A[i][j] / sig[j]; }
+    }
+    if (ngood == 3) {
+        // nothing to complete
+    } else if (ngood == 2) {
+        int z = !good[0] ? 0 : (!good[1] ? 1 : 2), a = (z + 1) % 3, b = (z + 2) % 3;
+        U[0][z] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
+        U[1][z] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
+        U[2][z] = U[0][a] * U[1][b] - U[1][a] * U[0][b];
+    } else {   // rank <= 1: no meaningful rotation; keep whatever direction exists, complete arbitrarily
+        double e[3] = {1, 0, 0};
+        int g = good[0] ? 0 : (good[1] ? 1 : (good[2] ? 2 : -1));
+        if (g < 0) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) U[i][j] = (i == j); }
+        else {
+            if (std::fabs(U[0][g]) > 0.9) { e[0] = 0; e[1] = 1; }
+            int a = (g + 1) % 3, b = (g + 2) % 3;
+            double n[3] = {U[1][g] * e[2] - U[2][g] * e[1], U[2][g] * e[0] - U[0][g] * e[2], U[0][g] * e[1] - U[1][g] * e[0]};
+            double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int i = 0; i < 3; ++i) U[i][a] = n[i] / nn;
+            U[0][b] = U[1][g] * U[2][a] - U[2][g] * U[1][a];
+            U[1][b] = U[2][g] * U[0][a] - U[0][g] * U[2][a];
+            U[2][b] = U[0][g] * U[1][a] - U[1][g] * U[0][a];
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Q[3 * i + j] = U[i][0] * V[j][0] + U[i][1] * V[j][1] + U[i][2] * V[j][2];
+    double rx = Q[7] - Q[5], ry = Q[2] - Q[6], rz = Q[3] - Q[1];
+    double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (Q[0] + Q[4] + Q[8] - 1.0) * 0.5;
+    if (s < 1e-5 && c > 0) {
+        for (int i = 0; i < 9; ++i) Q[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------- buffers
+template <class T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    void upload(const std::vector<T>& h, hipStream_t st) {
+        if (h.size() != n) alloc(h.size());
+        if (n) HIP_TRY(hipMemcpyAsync(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    void zero(hipStream_t st) { if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
+    ~DBuf() { release(); }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+};
+
+enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_COUNT };
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- handle
+struct sfmba_handle {
+    sfmba_options opt;
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool has_problem = false;
+    bool linearized = false;
+    double lin_lambda = 0.0;
+
+    // global shape and this partition
+    int64_t n_cam = 0, n_pts_all = 0, n_obs_all = 0;
+    int64_t pt_lo = 0, pt_hi = 0;          // owned point range
+    int n_pts = 0, n_obs = 0, n_chunks = 0, nb_cam = 0;
+    int chunk = kChunk;
+    std::vector<int> h_pm_orig;            // caller's observation index of each local observation
+
+    // device memory
+    DBuf<int> pt_ptr, pm_cam, pm_pt, pm_orig, cm_pt, chunk_cam, chunk_beg, cam_chunk_ptr;
+    DBuf<double2> pm_uv, cm_uv;
+    DBuf<double2> cams[2];
+    DBuf<double4> X[2];
+    DBuf<double> pm_sx, pm_sy, pm_siz, pm_ru, pm_rv, cm_sx, cm_sy, cm_siz;
+    DBuf<double> V, gp, Vinv, chunk_part, UG, T, Minv, rhs;
+    DBuf<double4> s, s0;
+    DBuf<double> px, pr, pz, pp, pq, qS;
+    DBuf<PcgState> pcg;
+    DBuf<double> dot_part, scal_part, scalars;
+    DBuf<double> tmp_a, tmp_b;             // API staging (residuals, Jacobian blocks, vectors)
+    int cur = 0;                           // index of the current parameter buffers
+    Dev dev{};
+
+    // communication
+    ncclComm_t comm = nullptr;
+
+    // timing
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { int fam; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double fam_ms[F_COUNT] = {};
+    int64_t fam_n[F_COUNT] = {};
+
+    ~sfmba_handle() {
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+using H = sfmba_handle;
+
+void refresh_dev(H* h) {
+    Dev& d = h->dev;
+    d.n_cam = (int)h->n_cam; d.n_pts = h->n_pts; d.n_obs = h->n_obs; d.n_chunks = h->n_chunks;
+    d.pt_ptr = h->pt_ptr.p; d.pm_cam = h->pm_cam.p; d.pm_pt = h->pm_pt.p; d.pm_orig = h->pm_orig.p;
+    d.pm_uv = h->pm_uv.p; d.cm_pt = h->cm_pt.p; d.cm_uv = h->cm_uv.p;
+    d.chunk_cam = h->chunk_cam.p; d.chunk_beg = h->chunk_beg.p; d.cam_chunk_ptr = h->cam_chunk_ptr.p;
+    d.cams = h->cams[h->cur].p; d.X = h->X[h->cur].p;
+    d.cams_trial = h->cams[h->cur ^ 1].p; d.X_trial = h->X[h->cur ^ 1].p;
+    d.pm_sx = h->pm_sx.p; d.pm_sy = h->pm_sy.p; d.pm_siz = h->pm_siz.p;
+    d.pm_ru = h->pm_ru.p; d.pm_rv = h->pm_rv.p;
+    d.cm_sx = h->cm_sx.p; d.cm_sy = h->cm_sy.p; d.cm_siz = h->cm_siz.p;
+    d.V = h->V.p; d.gp = h->gp.p; d.Vinv = h->Vinv.p; d.s = h->s.p; d.s0 = h->s0.p;
+    d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p;
+    d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp = h->pp.p; d.pq = h->pq.p; d.qS = h->qS.p;
+    d.pcg = h->pcg.p; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
+}
+
+// ---- timing spans -------------------------------------------------------------------------
+hipEvent_t next_event(H* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+struct Scope {
+    H* h; int fam; hipEvent_t a = nullptr;
+    Scope(H* h_, int fam_) : h(h_), fam(fam_) {
+        if (h->profile) { a = next_event(h); HIP_TRY(hipEventRecord(a, h->stream)); }
+        h->fam_n[fam]++;
+    }
+    ~Scope() {
+        if (h->profile && a) {
+            hipEvent_t b = nullptr;
+            if (h->ev_used < h->ev_pool.size()) b = h->ev_pool[h->ev_used++];
+            else if (hipEventCreate(&b) == hipSuccess) { h->ev_pool.push_back(b); h->ev_used++; }
+            if (b && hipEventRecord(b, h->stream) == hipSuccess) h->spans.push_back({fam, a, b});
+        }
+    }
+};
+void collect_spans(H* h) {
+    for (auto& s : h->spans) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        h->fam_ms[s.fam] += ms;
+    }
+    h->spans.clear();
+    h->ev_used = 0;
+}
+
+// ---- collectives --------------------------------------------------------------------------
+void allreduce(H* h, double* buf, size_t count) {
+    if (!h->comm || count == 0) return;
+    ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) fail(SFMBA_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+}
+
+void read_scalars(H* h, double* out) {
+    HIP_TRY(hipMemcpyAsync(out, h->scalars.p, SLOT_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+}
+
+// Sum the partition-local scalar slots over ranks (the camera slots are replicated already).
+void reduce_scalars(H* h, int first, int count) {
+    if (!h->comm) return;
+    allreduce(h, h->scalars.p + first, (size_t)count);
+}
+
+// ---- solver phases ------------------------------------------------------------------------
+// Linearise at the current estimate: seeds, residuals, V_p, g_p, U_c, g_c.  Leaves the cost sum
+// in scalars[SLOT_COST] (this partition's part) and max|g_p| in scalars[SLOT_GMAX_PT].
+void phase_linearize(H* h) {
+    Scope t(h, F_LIN);
+    refresh_dev(h);
+    launch_lin_pm(h->dev, h->stream);
+    launch_lin_cm(h->dev, h->stream);
+    launch_chunk_reduce(h->dev, 27, h->UG.p, h->stream);
+    allreduce(h, h->UG.p, (size_t)h->n_cam * 27);
+    h->linearized = false;
+}
+
+// Damp with lambda: Vinv, V*^-1 g_p, block-Jacobi blocks, reduced right-hand side.
+void phase_damp(H* h, double lambda) {
+    Scope t(h, F_DAMP);
+    launch_damp_pm(h->dev, lambda, h->stream);
+    launch_sdiag_cm(h->dev, h->stream);
+    launch_chunk_reduce(h->dev, 27, h->T.p, h->stream);
+    allreduce(h, h->T.p, (size_t)h->n_cam * 27);
+    launch_precond(h->dev, lambda, h->stream);
+    h->linearized = true;
+    h->lin_lambda = lambda;
+}
+
+// qS = sum over observations of W Vinv W' x (this partition's part, then all ranks').
+void schur_product(H* h, const double* x, bool check_done) {
+    {
+        Scope t(h, F_SPMV_PM);
+        launch_spmv_pm(h->dev, x, check_done, h->stream);
+    }
+    {
+        Scope t(h, F_SPMV_CM);
+        launch_spmv_cm(h->dev, check_done, h->stream);
+    }
+    {
+        Scope t(h, F_PCGVEC);
+        launch_chunk_reduce(h->dev, 6, h->qS.p, h->stream);
+    }
+    allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
+}
+
+// Block-Jacobi PCG on S dc = rhs; result in px.  Returns the iteration count.
+int phase_pcg(H* h, double lambda) {
+    const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
+    const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
+    {
+        Scope t(h, F_PCGVEC);
+        launch_pcg_init(h->dev, tol, max_iter, h->stream);
+    }
+    int cur = 0, queued = 0, batch = 4;
+    PcgState st{};
+    for (;;) {
+        for (int i = 0; i < batch; ++i) {
+            schur_product(h, h->pp.p, true);
+            Scope t(h, F_PCGVEC);
+            launch_pcg_q(h->dev, lambda, cur, h->stream);
+            launch_pcg_update(h->dev, cur, h->stream);
+            launch_pcg_dir(h->dev, cur, h->stream);
+            cur ^= 1;
+            ++queued;
+        }
+        HIP_TRY(hipMemcpyAsync(&st, h->pcg.p + cur, sizeof st, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (st.done || queued >= max_iter + batch) break;
+        if (batch < 32) batch *= 2;
+    }
+    return st.iter;
+}
+
+// Step evaluation: back-substitution, retraction into the trial buffers, trial cost.
+void phase_trial(H* h, double* dp_out) {
+    {
+        Scope t(h, F_BACK);
+        launch_back_pm(h->dev, h->px.p, dp_out, h->stream);
+        launch_cam_update(h->dev, h->px.p, h->stream);
+    }
+    {
+        Scope t(h, F_COST);
+        launch_cost_pm(h->dev, h->stream);
+    }
+    reduce_scalars(h, SLOT_MODEL, SLOT_NONFINITE - SLOT_MODEL + 1);
+}
+
+double gather_gmax_pt(H* h, double local) {
+    // max over ranks of a non-negative scalar through a sum all-reduce of one slot per rank
+    if (!h->comm) return local;
+    int nr = h->opt.nranks;
+    std::vector<double> slots(nr, 0.0);
+    slots[h->opt.rank] = local;
+    HIP_TRY(hipMemcpyAsync(h->tmp_b.p, slots.data(), nr * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    allreduce(h, h->tmp_b.p, nr);
+    HIP_TRY(hipMemcpyAsync(slots.data(), h->tmp_b.p, nr * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double m = 0;
+    for (double v : slots) m = std::max(m, v);
+    return m;
+}
+
+void print_header() {
+    printf("%s\n", "   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality   ");
+}
+void print_row(int it, int nfev, double cost, double red, double step, double opt, bool first) {
+    if (first) printf("%8d     %10d      %13.4e                                 %10.2e    \n", it, nfev, cost, opt);
+    else printf("%8d     %10d      %13.4e    %10.2e     %10.2e     %10.2e    \n", it, nfev, cost, red, step, opt);
+}
+
+void do_solve(H* h, sfmba_stats* out) {
+    if (!h->has_problem) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_solve: no problem set");
+    HIP_TRY(hipSetDevice(h->device));
+    const sfmba_options& o = h->opt;
+    const double ftol = o.ftol, xtol = o.xtol, gtol = o.gtol;
+    const int64_t n_par = 12 * h->n_cam + 3 * h->n_pts_all;
+    const int64_t max_nfev = o.max_nfev > 0 ? o.max_nfev : 100 * n_par;
+    const int max_it = o.max_iterations > 0 ? o.max_iterations : 200;
+    double lambda = o.initial_lambda > 0 ? o.initial_lambda : 1e-4;
+    double nu = 2.0;
+    sfmba_stats st{};
+    st.linear_solver = SFMBA_SOLVER_PCG;
+    for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
+    h->profile = o.profile != 0;
+    if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
+    auto t0 = std::chrono::steady_clock::now();
+    double sc[SLOT_COUNT];
+
+    phase_linearize(h);
+    st.njev = 1;
+    reduce_scalars(h, SLOT_COST, 1);
+    read_scalars(h, sc);
+    double cost = 0.5 * sc[SLOT_COST];
+    double gmax_pt = gather_gmax_pt(h, sc[SLOT_GMAX_PT]);
+    st.nfev = 1;
+    st.initial_cost = cost;
+    if (!std::isfinite(cost)) fail(SFMBA_ERR_NONFINITE, "Residuals are not finite in the initial point.");
+    int status = -1;
+    double g_norm = 0.0, step_norm = 0.0, actual = 0.0;
+    bool fresh = true;     // a linearisation not yet tested against gtol
+    if (o.verbose >= 2 && o.rank <= 0) print_header();
+    int accepted = 0;
+    for (int it = 0; it < max_it && status < 0; ++it) {
+        phase_damp(h, lambda);
+        if (fresh) {
+            read_scalars(h, sc);
+            g_norm = std::max(sc[SLOT_GMAX_CAM], gmax_pt);
+            fresh = false;
+            if (o.verbose >= 2 && o.rank <= 0) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, accepted == 0);
+            if (g_norm < gtol) { status = SFMBA_STATUS_GTOL; break; }
+            if (st.nfev >= max_nfev) { status = SFMBA_STATUS_MAX_NFEV; break; }
+        }
+        st.pcg_iterations += phase_pcg(h, lambda);
+        phase_trial(h, nullptr);
+        read_scalars(h, sc);
+        st.nfev++;
+        st.iterations++;
+        const double model_cost = 0.5 * sc[SLOT_MODEL];
+        const double cost_new = sc[SLOT_NONFINITE] > 0 ? std::numeric_limits<double>::infinity() : 0.5 * sc[SLOT_TRIAL];
+        const double pred = cost - model_cost;
+        actual = cost - cost_new;
+        const double rho = (pred > 0 && std::isfinite(cost_new)) ? actual / pred : -1.0;
+        step_norm = std::sqrt(sc[SLOT_STEP2_PT] + sc[SLOT_STEP2_CAM]);
+        const double x_norm = std::sqrt(sc[SLOT_X2_PT] + sc[SLOT_X2_CAM]);
+        const bool ft = actual < ftol * cost && rho > 0.25;
+        const bool xt = step_norm < xtol * (xtol + x_norm);
+        if (o.verbose >= 3 && o.rank <= 0)
+            printf("  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e\n", it, cost, cost_new, rho, lambda, step_norm);
+        if (rho > 1e-3) {
+            h->cur ^= 1;
+            ++accepted;
+            lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-15);
+            nu = 2.0;
+            cost = cost_new;
+            phase_linearize(h);
+            st.njev++;
+            reduce_scalars(h, SLOT_COST, 1);
+            read_scalars(h, sc);
+            gmax_pt = gather_gmax_pt(h, sc[SLOT_GMAX_PT]);
+            fresh = true;
+            if (ft && xt) status = SFMBA_STATUS_FTOL_XTOL;
+            else if (ft) status = SFMBA_STATUS_FTOL;
+            else if (xt) status = SFMBA_STATUS_XTOL;
+        } else {
+            lambda *= nu;
+            nu *= 2.0;
+            if (xt || lambda > 1e32) status = SFMBA_STATUS_XTOL;
+        }
+        if (status < 0 && st.nfev >= max_nfev) status = SFMBA_STATUS_MAX_NFEV;
+    }
+    if (status < 0) status = SFMBA_STATUS_MAX_NFEV;
+    if (fresh) {   // gradient norm at the final iterate
+        phase_damp(h, lambda);
+        read_scalars(h, sc);
+        g_norm = std::max(sc[SLOT_GMAX_CAM], gmax_pt);
+        if (o.verbose >= 2 && o.rank <= 0) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, accepted == 0);
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    auto t1 = std::chrono::steady_clock::now();
+    if (h->profile) collect_spans(h);
+    st.status = status;
+    st.accepted = accepted;
+    st.final_cost = cost;
+    st.optimality = g_norm;
+    st.solve_seconds = std::chrono::duration<double>(t1 - t0).count();
+    st.ms_linearize = h->fam_ms[F_LIN]; st.n_linearize = h->fam_n[F_LIN];
+    st.ms_damp = h->fam_ms[F_DAMP]; st.n_damp = h->fam_n[F_DAMP];
+    st.ms_spmv_pm = h->fam_ms[F_SPMV_PM]; st.n_spmv_pm = h->fam_n[F_SPMV_PM];
+    st.ms_spmv_cm = h->fam_ms[F_SPMV_CM]; st.n_spmv_cm = h->fam_n[F_SPMV_CM];
+    st.ms_pcg_vec = h->fam_ms[F_PCGVEC]; st.n_pcg_vec = h->fam_n[F_PCGVEC];
+    st.ms_back = h->fam_ms[F_BACK]; st.n_back = h->fam_n[F_BACK];
+    st.ms_cost = h->fam_ms[F_COST]; st.n_cost = h->fam_n[F_COST];
+    st.ms_dense = h->fam_ms[F_DENSE]; st.n_dense = h->fam_n[F_DENSE];
+    if (o.verbose >= 1 && o.rank <= 0) {
+        static const char* msg[] = {"The maximum number of function evaluations is exceeded.",
+                                    "`gtol` termination condition is satisfied.",
+                                    "`ftol` termination condition is satisfied.",
+                                    "`xtol` termination condition is satisfied.",
+                                    "Both `ftol` and `xtol` termination conditions are satisfied."};
+        printf("%s\nFunction evaluations %d, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n",
+               msg[status], st.nfev, st.initial_cost, st.final_cost, st.optimality);
+    }
+    if (out) *out = st;
+}
+
+// ---- problem packing ----------------------------------------------------------------------
+void pack_cameras(H* h, const double* camera_params, std::vector<double2>& out) {
+    out.resize((size_t)h->n_cam * 6);
+    for (int64_t c = 0; c < h->n_cam; ++c) {
+        double Q[9];
+        const double* cp = camera_params + 12 * c;
+        for (int i = 0; i < 12; ++i)
+            if (!std::isfinite(cp[i])) fail(SFMBA_ERR_NONFINITE, "camera_params[%lld] is not finite", (long long)c);
+        polar3(cp, Q);
+        double v[12] = {Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7], Q[8], cp[9], cp[10], cp[11]};
+        for (int i = 0; i < 6; ++i) out[6 * c + i] = make_double2(v[2 * i], v[2 * i + 1]);
+    }
+}
+
+void do_set_params(H* h, const double* camera_params, const double* points_3d) {
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<double2> cams;
+    pack_cameras(h, camera_params, cams);
+    std::vector<double4> X((size_t)h->n_pts);
+    for (int p = 0; p < h->n_pts; ++p) {
+        const double* x = points_3d + 3 * (h->pt_lo + p);
+        X[p] = make_double4(x[0], x[1], x[2], 0.0);
+    }
+    h->cur = 0;
+    h->cams[0].upload(cams, h->stream);
+    h->cams[1].alloc(cams.size());
+    h->X[0].upload(X, h->stream);
+    h->X[1].alloc(X.size());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->linearized = false;
+    refresh_dev(h);
+}
+
+void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const double* camera_params,
+                    const double* points_3d, const int64_t* cam_idx, const int64_t* pt_idx,
+                    const double* points_2d, const double* K) {
+    if (n_cam <= 0 || n_pts <= 0 || n_obs < 0) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes must be positive");
+    if (!camera_params || !points_3d || !K || (n_obs > 0 && (!cam_idx || !pt_idx || !points_2d)))
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: null array");
+    if (n_obs > 2000000000LL || n_pts > 2000000000LL || n_cam > 50000000LL)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes exceed 32-bit indexing");
+    HIP_TRY(hipSetDevice(h->device));
+    h->has_problem = false;
+    for (int64_t i = 0; i < n_obs; ++i) {
+        if (cam_idx[i] < 0 || cam_idx[i] >= n_cam)
+            fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)cam_idx[i], (long long)n_cam);
+        if (pt_idx[i] < 0 || pt_idx[i] >= n_pts)
+            fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)pt_idx[i], (long long)n_pts);
+    }
+    h->n_cam = n_cam; h->n_pts_all = n_pts; h->n_obs_all = n_obs;
+    h->dev.K = Intr{K[0], K[4], K[2], K[5]};
+
+    // observations per point, then the owned point range: contiguous, equal observation share
+    std::vector<int> cnt((size_t)n_pts + 1, 0);
+    for (int64_t i = 0; i < n_obs; ++i) cnt[pt_idx[i] + 1]++;
+    std::vector<int64_t> pre((size_t)n_pts + 1, 0);
+    for (int64_t p = 0; p < n_pts; ++p) pre[p + 1] = pre[p] + cnt[p + 1];
+    const int nr = std::max(1, h->opt.nranks), rk = nr > 1 ? h->opt.rank : 0;
+    auto boundary = [&](int r) -> int64_t {
+        if (r <= 0) return 0;
+        if (r >= nr) return n_pts;
+        int64_t target = (int64_t)((double)n_obs * r / nr);
+        return std::lower_bound(pre.begin(), pre.end(), target) - pre.begin();
+    };
+    h->pt_lo = std::min(boundary(rk), n_pts);
+    h->pt_hi = std::min(std::max(boundary(rk + 1), h->pt_lo), n_pts);
+    h->n_pts = (int)(h->pt_hi - h->pt_lo);
+    h->n_obs = (int)(pre[h->pt_hi] - pre[h->pt_lo]);
+    const int np = h->n_pts, no = h->n_obs;
+
+    // point-major order of the owned observations (stable counting sort by point)
+    std::vector<int> pt_ptr((size_t)np + 1);
+    for (int p = 0; p <= np; ++p) pt_ptr[p] = (int)(pre[h->pt_lo + p] - pre[h->pt_lo]);
+    std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
+    std::vector<int> pm_cam(no), pm_pt(no), pm_orig(no);
+    std::vector<double2> pm_uv(no);
+    for (int64_t i = 0; i < n_obs; ++i) {
+        int64_t p = pt_idx[i];
+        if (p < h->pt_lo || p >= h->pt_hi) continue;
+        int j = fill[p - h->pt_lo]++;
+        pm_cam[j] = (int)cam_idx[i];
+        pm_pt[j] = (int)(p - h->pt_lo);
+        pm_orig[j] = (int)i;
+        pm_uv[j] = make_double2(points_2d[2 * i], points_2d[2 * i + 1]);
+    }
+    // camera-major order (stable counting sort of the point-major list by camera)
+    std::vector<int> cam_ptr((size_t)n_cam + 1, 0);
+    for (int j = 0; j < no; ++j) cam_ptr[pm_cam[j] + 1]++;
+    for (int64_t c = 0; c < n_cam; ++c) cam_ptr[c + 1] += cam_ptr[c];
+    std::vector<int> cfill(cam_ptr.begin(), cam_ptr.end() - 1);
+    std::vector<int> cm_pt(no);
+    std::vector<double2> cm_uv(no);
+    for (int j = 0; j < no; ++j) {
+        int k = cfill[pm_cam[j]]++;
+        cm_pt[k] = pm_pt[j];
+        cm_uv[k] = pm_uv[j];
+    }
+    // chunks: pieces of at most `chunk` observations of one camera
+    if (const char* e = getenv("SFMBA_CHUNK")) { int v = atoi(e); if (v >= 64) h->chunk = v; }
+    std::vector<int> chunk_cam, chunk_beg, cam_chunk_ptr((size_t)n_cam + 1, 0);
+    for (int64_t c = 0; c < n_cam; ++c) {
+        cam_chunk_ptr[c] = (int)chunk_cam.size();
+        for (int b = cam_ptr[c]; b < cam_ptr[c + 1]; b += h->chunk) { chunk_cam.push_back((int)c); chunk_beg.push_back(b); }
+    }
+    cam_chunk_ptr[n_cam] = (int)chunk_cam.size();
+    chunk_beg.push_back(no);
+    h->n_chunks = (int)chunk_cam.size();
+    h->nb_cam = (int)((n_cam + kBlock - 1) / kBlock);
+    if ((np + kBlock - 1) / kBlock > kMaxScalBlocks) fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many points for one GPU");
+
+    hipStream_t st = h->stream;
+    h->pt_ptr.upload(pt_ptr, st); h->pm_cam.upload(pm_cam, st); h->pm_pt.upload(pm_pt, st);
+    h->pm_orig.upload(pm_orig, st); h->pm_uv.upload(pm_uv, st);
+    h->cm_pt.upload(cm_pt, st); h->cm_uv.upload(cm_uv, st);
+    h->chunk_cam.upload(chunk_cam, st); h->chunk_beg.upload(chunk_beg, st); h->cam_chunk_ptr.upload(cam_chunk_ptr, st);
+    h->h_pm_orig.swap(pm_orig);
+    for (DBuf<double>* b : {&h->pm_sx, &h->pm_sy, &h->pm_siz, &h->pm_ru, &h->pm_rv, &h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
+    h->V.alloc((size_t)np * 6); h->gp.alloc((size_t)np * 4); h->Vinv.alloc((size_t)np * 6);
+    h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
+    h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * 27);
+    h->UG.alloc((size_t)n_cam * 27); h->T.alloc((size_t)n_cam * 27);
+    h->Minv.alloc((size_t)n_cam * 36); h->rhs.alloc((size_t)n_cam * 6);
+    for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp, &h->pq, &h->qS}) b->alloc((size_t)n_cam * 6);
+    h->pcg.alloc(2); h->dot_part.alloc((size_t)2 * h->nb_cam);
+    h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
+    h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
+    h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * 36));
+    HIP_TRY(hipStreamSynchronize(st));
+    do_set_params(h, camera_params, points_3d);
+    h->has_problem = true;
+}
+
+template <class F>
+int guarded(sfmba_handle* h, F&& f) {
+    if (!h) return SFMBA_ERR_INVALID_ARGUMENT;
+    try {
+        f();
+        return SFMBA_OK;
+    } catch (const ApiError& e) {
+        h->err = e.msg;
+        return e.code;
+    } catch (const HipError& e) {
+        h->err = std::string(e.what) + ": " + hipGetErrorString(e.e);
+        return SFMBA_ERR_HIP;
+    } catch (const std::bad_alloc&) {
+        h->err = "out of host memory";
+        return SFMBA_ERR_INVALID_ARGUMENT;
+    } catch (...) {
+        h->err = "unexpected exception";
+        return SFMBA_ERR_INVALID_ARGUMENT;
+    }
+}
+
+void need_problem(H* h, const char* who) {
+    if (!h->has_problem) fail(SFMBA_ERR_INVALID_ARGUMENT, "%s: no problem set", who);
+    HIP_TRY(hipSetDevice(h->device));
+}
+void need_linearized(H* h, const char* who) {
+    need_problem(h, who);
+    if (!h->linearized) fail(SFMBA_ERR_INVALID_ARGUMENT, "%s: call sfmba_linearize first", who);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+void sfmba_default_options(sfmba_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->ftol = 1e-4; o->xtol = 1e-12; o->gtol = 1e-8; o->max_nfev = 0;
+    o->max_iterations = 200; o->initial_lambda = 1e-4; o->pcg_rtol = 0.1; o->pcg_max_iter = 1000;
+    o->linear_solver = SFMBA_SOLVER_AUTO; o->dense_max_dim = 1536; o->verbose = 0; o->profile = 0; o->device = -1;
+    o->rank = 0; o->nranks = 1;
+}
+
+int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
+    if (!out) return SFMBA_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    sfmba_handle* h = new (std::nothrow) sfmba_handle();
+    if (!h) return SFMBA_ERR_INVALID_ARGUMENT;
+    if (opts) h->opt = *opts; else sfmba_default_options(&h->opt);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete h; return SFMBA_ERR_NO_DEVICE; }
+    int dev = h->opt.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= n) { delete h; return SFMBA_ERR_NO_DEVICE; }
+    h->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return SFMBA_ERR_HIP;
+    }
+    *out = h;
+    return SFMBA_OK;
+}
+
+int sfmba_destroy(sfmba_handle* h) {
+    if (!h) return SFMBA_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(h->device);
+    delete h;
+    return SFMBA_OK;
+}
+
+const char* sfmba_last_error(const sfmba_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
+                      const double* camera_params, const double* points_3d,
+                      const int64_t* camera_indices, const int64_t* point_indices,
+                      const double* points_2d, const double* K) {
+    return guarded(h, [&] {
+        do_set_problem(h, n_cameras, n_points, n_obs, camera_params, points_3d, camera_indices, point_indices, points_2d, K);
+    });
+}
+
+int sfmba_set_params(sfmba_handle* h, const double* camera_params, const double* points_3d) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_set_params");
+        if (!camera_params || !points_3d) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_params: null array");
+        do_set_params(h, camera_params, points_3d);
+    });
+}
+
+int sfmba_residuals(sfmba_handle* h, double* out) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_residuals");
+        if (!out) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_residuals: null output");
+        refresh_dev(h);
+        const size_t n = 2 * (size_t)h->n_obs_all;
+        if (h->tmp_a.n < n) h->tmp_a.alloc(n);
+        const bool whole = h->n_obs == h->n_obs_all;
+        if (!whole) HIP_TRY(hipMemcpyAsync(h->tmp_a.p, out, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_residuals(h->dev, h->tmp_a.p, h->stream);
+        HIP_TRY(hipMemcpyAsync(out, h->tmp_a.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_jacobian_blocks(sfmba_handle* h, double* jac_cam, double* jac_pt) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_jacobian_blocks");
+        if (!jac_cam || !jac_pt) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_jacobian_blocks: null output");
+        refresh_dev(h);
+        const size_t n = (size_t)h->n_obs_all;
+        DBuf<double> jc, jp;
+        jc.alloc(12 * n); jp.alloc(6 * n);
+        if (h->n_obs != h->n_obs_all) {
+            HIP_TRY(hipMemcpyAsync(jc.p, jac_cam, 12 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(jp.p, jac_pt, 6 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+        launch_jacobian_blocks(h->dev, jc.p, jp.p, h->stream);
+        HIP_TRY(hipMemcpyAsync(jac_cam, jc.p, 12 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(jac_pt, jp.p, 6 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_solve(sfmba_handle* h, sfmba_stats* stats) {
+    return guarded(h, [&] { do_solve(h, stats); });
+}
+
+int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_get_params");
+        if (camera_params) {
+            HIP_TRY(hipMemcpyAsync(camera_params, h->cams[h->cur].p, (size_t)h->n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        if (points_3d) {
+            std::vector<double4> X((size_t)h->n_pts);
+            if (h->n_pts) HIP_TRY(hipMemcpyAsync(X.data(), h->X[h->cur].p, X.size() * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->comm) {
+                // every rank returns all points: sum of zero-padded full-length arrays
+                std::vector<double> full((size_t)h->n_pts_all * 3, 0.0);
+                for (int p = 0; p < h->n_pts; ++p) {
+                    double* o = full.data() + 3 * (h->pt_lo + p);
+                    o[0] = X[p].x; o[1] = X[p].y; o[2] = X[p].z;
+                }
+                DBuf<double> d;
+                d.alloc(full.size());
+                HIP_TRY(hipMemcpyAsync(d.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                allreduce(h, d.p, full.size());
+                HIP_TRY(hipMemcpyAsync(points_3d, d.p, full.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            } else {
+                for (int p = 0; p < h->n_pts; ++p) {
+                    double* o = points_3d + 3 * (h->pt_lo + p);
+                    o[0] = X[p].x; o[1] = X[p].y; o[2] = X[p].z;
+                }
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_linearize(sfmba_handle* h, double lambda) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_linearize");
+        phase_linearize(h);
+        phase_damp(h, lambda);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, double* g_pt) {
+    return guarded(h, [&] {
+        need_linearized(h, "sfmba_get_blocks");
+        if (U || g_cam) {
+            std::vector<double> ug((size_t)h->n_cam * 27);
+            HIP_TRY(hipMemcpy(ug.data(), h->UG.p, ug.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int64_t c = 0; c < h->n_cam; ++c) {
+                const double* u = ug.data() + 27 * c;
+                if (U) {
+                    int n = 0;
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i; j < 6; ++j) { U[36 * c + 6 * i + j] = u[n]; U[36 * c + 6 * j + i] = u[n]; ++n; }
+                }
+                if (g_cam) for (int i = 0; i < 6; ++i) g_cam[6 * c + i] = u[21 + i];
+            }
+        }
+        if (V) {
+            std::vector<double> v((size_t)h->n_pts * 6);
+            if (h->n_pts) HIP_TRY(hipMemcpy(v.data(), h->V.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int p = 0; p < h->n_pts; ++p) {
+                const double* a = v.data() + 6 * (size_t)p;
+                double* o = V + 9 * (h->pt_lo + p);
+                o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[1]; o[4] = a[3]; o[5] = a[4]; o[6] = a[2]; o[7] = a[4]; o[8] = a[5];
+            }
+        }
+        if (g_pt) {
+            std::vector<double> g((size_t)h->n_pts * 4);
+            if (h->n_pts) HIP_TRY(hipMemcpy(g.data(), h->gp.p, g.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int p = 0; p < h->n_pts; ++p)
+                for (int i = 0; i < 3; ++i) g_pt[3 * (h->pt_lo + p) + i] = g[4 * (size_t)p + i];
+        }
+    });
+}
+
+int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y) {
+    return guarded(h, [&] {
+        need_linearized(h, "sfmba_schur_matvec");
+        if (!x || !y) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_schur_matvec: null array");
+        const size_t n = (size_t)h->n_cam * 6;
+        HIP_TRY(hipMemcpyAsync(h->pz.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        schur_product(h, h->pz.p, false);
+        launch_schur_apply(h->dev, h->pz.p, h->lin_lambda, h->pq.p, h->stream);
+        HIP_TRY(hipMemcpyAsync(y, h->pq.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_get_reduced(sfmba_handle* h, double* rhs, double* precond_inv) {
+    return guarded(h, [&] {
+        need_linearized(h, "sfmba_get_reduced");
+        if (rhs) HIP_TRY(hipMemcpy(rhs, h->rhs.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost));
+        if (precond_inv) HIP_TRY(hipMemcpy(precond_inv, h->Minv.p, (size_t)h->n_cam * 36 * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t* pcg_iters) {
+    return guarded(h, [&] {
+        need_linearized(h, "sfmba_solve_step");
+        int it = phase_pcg(h, h->lin_lambda);
+        if (pcg_iters) *pcg_iters = it;
+        DBuf<double> dp;
+        dp.alloc((size_t)std::max(h->n_pts, 1) * 3);
+        phase_trial(h, dp.p);
+        if (step_cam) HIP_TRY(hipMemcpyAsync(step_cam, h->px.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (step_pt && h->n_pts)
+            HIP_TRY(hipMemcpyAsync(step_pt + 3 * h->pt_lo, dp.p, (size_t)h->n_pts * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_comm_unique_id(void* out128) {
+    if (!out128) return SFMBA_ERR_INVALID_ARGUMENT;
+    std::string err;
+    if (!g_rccl.load(err)) return SFMBA_ERR_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return SFMBA_ERR_COMM;
+    memcpy(out128, &id, sizeof id);
+    return SFMBA_OK;
+}
+
+int sfmba_comm_init(sfmba_handle* h, const void* unique_id128) {
+    return guarded(h, [&] {
+        if (!unique_id128) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_comm_init: null id");
+        if (h->opt.nranks < 1 || h->opt.rank < 0 || h->opt.rank >= h->opt.nranks)
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_comm_init: rank %d of %d", h->opt.rank, h->opt.nranks);
+        std::string err;
+        if (!g_rccl.load(err)) fail(SFMBA_ERR_COMM, "%s", err.c_str());
+        HIP_TRY(hipSetDevice(h->device));
+        ncclUniqueId id;
+        memcpy(&id, unique_id128, sizeof id);
+        ncclResult_t r = g_rccl.CommInitRank(&h->comm, h->opt.nranks, id, h->opt.rank);
+        if (r != ncclSuccess) { h->comm = nullptr; fail(SFMBA_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    });
+}
+
+}  // extern "C"

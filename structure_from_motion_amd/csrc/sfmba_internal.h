@@ -1,0 +1,109 @@
+// Host/device shared declarations of libsfmba: the HBM layout of one problem partition and the
+// launch wrappers of every kernel family.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sfmba_device.h"
+
+namespace sfmba {
+
+constexpr int kBlock = 256;        // threads per workgroup of every kernel (4 wavefronts)
+constexpr int kChunk = 512;        // observations per camera-major chunk (one wavefront each)
+constexpr int kMaxScalBlocks = 65536;
+
+// Scalar reduction slots (block partials -> k_scal_finalize -> scalars[slot]).
+enum Slot {
+    SLOT_COST = 0,      // sum r^2 at the linearisation point
+    SLOT_GMAX_PT,       // max |g_p|
+    SLOT_MODEL,         // sum (r + J step)^2
+    SLOT_STEP2_PT,      // sum |dp|^2
+    SLOT_X2_PT,         // sum |X|^2
+    SLOT_TRIAL,         // sum r^2 at the trial point
+    SLOT_NONFINITE,     // count of non-finite trial residuals
+    SLOT_STEP2_CAM,     // sum |dc|^2
+    SLOT_X2_CAM,        // sum |t|^2 (+3 per camera for the rotation block)
+    SLOT_GMAX_CAM,      // max |g_c|
+    SLOT_COUNT
+};
+
+// PCG state kept in device memory so that the host can queue iterations without reading back.
+struct PcgState {
+    double rz;        // r'z of the current iterate
+    double rz0;       // r'z at iteration 0
+    double tol2;      // stop when rz <= tol2 * rz0
+    int iter;
+    int max_iter;
+    int done;
+    int pad;
+};
+
+// Everything a kernel needs, passed by value.  "pm" arrays are in point-major observation
+// order (observations of one point contiguous), "cm" arrays in camera-major order.
+struct Dev {
+    int n_cam;            // all cameras (replicated on every rank)
+    int n_pts;            // points owned by this partition
+    int n_obs;            // observations of the owned points
+    int n_chunks;         // camera-major chunks
+    Intr K;
+    // static structure
+    const int* pt_ptr;        // [n_pts+1] CSR offsets into pm arrays
+    const int* pm_cam;        // [n_obs]
+    const int* pm_pt;         // [n_obs] local point id
+    const int* pm_orig;       // [n_obs] caller's observation index
+    const double2* pm_uv;     // [n_obs]
+    const int* cm_pt;         // [n_obs] local point id
+    const double2* cm_uv;     // [n_obs]
+    const int* chunk_cam;     // [n_chunks]
+    const int* chunk_beg;     // [n_chunks+1] offsets into cm arrays (chunk q = [beg[q], beg[q+1]))
+    const int* cam_chunk_ptr; // [n_cam+1] chunk range of each camera
+    // parameters (current and trial)
+    const double2* cams;      // [n_cam][12]
+    const double4* X;         // [n_pts] (x, y, z, pad)
+    double2* cams_trial;
+    double4* X_trial;
+    // linearisation products
+    double* pm_sx; double* pm_sy; double* pm_siz;   // seeds, point-major
+    double* pm_ru; double* pm_rv;                   // residuals, point-major
+    double* cm_sx; double* cm_sy; double* cm_siz;   // seeds, camera-major
+    double* V;          // [n_pts][6] packed upper J_p'J_p
+    double* gp;         // [n_pts][4]
+    double* Vinv;       // [n_pts][6] (V + lambda D)^-1
+    double4* s;         // [n_pts] work vector of the matvec / V*^-1 g_p
+    double4* s0;        // [n_pts] V*^-1 g_p
+    double* chunk_part; // [n_chunks][27]
+    double* UG;         // [n_cam][27]: 21 packed upper J_c'J_c | 6 g_c (all ranks' sum)
+    double* T;          // [n_cam][27]: 21 sum W V*^-1 W' | 6 sum W V*^-1 g_p
+    double* Minv;       // [n_cam][36] inverse of the block-Jacobi blocks
+    double* rhs;        // [n_cam][6]
+    // PCG vectors, [n_cam][6]
+    double* px; double* pr; double* pz; double* pp; double* pq; double* qS;
+    PcgState* pcg;      // [2], double-buffered by iteration parity
+    double* dot_part;   // [2][ceil(n_cam/kBlock)] block partials of p'q and r'z
+    // scalars
+    double* scal_part;  // [SLOT_COUNT][kMaxScalBlocks]
+    double* scalars;    // [SLOT_COUNT]
+};
+
+// ---- launch wrappers (sfmba_kernels.hip) -------------------------------------------------
+void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);
+void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStream_t st);
+void launch_lin_pm(const Dev& d, hipStream_t st);
+void launch_lin_cm(const Dev& d, hipStream_t st);               // chunk partials (27 values)
+void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
+void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);
+void launch_sdiag_cm(const Dev& d, hipStream_t st);             // chunk partials (27 values)
+void launch_precond(const Dev& d, double lambda, hipStream_t st);
+void launch_spmv_pm(const Dev& d, const double* x, bool check_done, hipStream_t st);
+void launch_spmv_cm(const Dev& d, bool check_done, hipStream_t st);   // chunk partials (6 values)
+void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st);
+void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);
+void launch_pcg_update(const Dev& d, int cur, hipStream_t st);
+void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);
+void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
+void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
+void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
+void launch_cost_pm(const Dev& d, hipStream_t st);
+int scal_blocks_pt(const Dev& d);
+
+}  // namespace sfmba

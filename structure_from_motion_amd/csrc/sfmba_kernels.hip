@@ -1,0 +1,689 @@
+// HIP kernels of libsfmba for gfx950 (MI355X).  fp64 throughout.
+//
+// Two observation orders are kept in HBM.  Point-major ("pm"): the observations of one point
+// are contiguous, one thread owns one point and keeps its 3x3 block and 3-vector sums in
+// registers.  Camera-major ("cm"): the observations of one camera are contiguous and cut into
+// chunks of at most kChunk; one 64-lane wavefront owns one chunk, the camera is wave-uniform,
+// per-observation 6-vector / 6x6 contributions are summed in registers, reduced across the
+// wavefront with cross-lane shuffles and written as one partial row per chunk; a per-camera
+// pass adds the chunk rows in a fixed order, so every sum is bitwise reproducible.
+//
+// What the kernels replace in the reference: the per-observation residual loop
+// (/root/reference/bundle_adjustment.py:22-30,49-50), SciPy's finite-difference Jacobian over
+// the jac_sparsity pattern (bundle_adjustment.py:53-74,139-141) and the LSMR trust-region step
+// (scipy/optimize/_lsq/trf.py:471-499).
+#include "sfmba_internal.h"
+
+namespace sfmba {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Store one block partial of a scalar slot.
+__device__ __forceinline__ void put_partial(const Dev& d, int slot, double v) {
+    d.scal_part[(size_t)slot * kMaxScalBlocks + blockIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fun() parity: residuals in the caller's observation order.
+__global__ __launch_bounds__(kBlock) void k_residuals(Dev d, double* __restrict__ out) {
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= d.n_obs) return;
+    double4 X = d.X[d.pm_pt[j]];
+    Cam k = load_cam(d.cams, d.pm_cam[j]);
+    Seed s = project_seed(k, X.x, X.y, X.z);
+    double2 uv = d.pm_uv[j];
+    double ru, rv;
+    residual(s, d.K, uv.x, uv.y, ru, rv);
+    size_t o = 2 * (size_t)d.pm_orig[j];
+    out[o] = ru;
+    out[o + 1] = rv;
+}
+
+__global__ __launch_bounds__(kBlock) void k_jacobian_blocks(Dev d, double* __restrict__ jc_out,
+                                                            double* __restrict__ jp_out) {
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= d.n_obs) return;
+    double4 X = d.X[d.pm_pt[j]];
+    Cam k = load_cam(d.cams, d.pm_cam[j]);
+    Seed s = project_seed(k, X.x, X.y, X.z);
+    double jc[12], a[3], b[3];
+    jac_cam(s, d.K, jc);
+    jac_pt(s, d.K, k.q, a, b);
+    size_t o = (size_t)d.pm_orig[j];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) jc_out[12 * o + i] = jc[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { jp_out[6 * o + i] = a[i]; jp_out[6 * o + 3 + i] = b[i]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Linearisation, point-major half: seeds + residuals per observation, V_p and g_p per point.
+__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
+    __shared__ double red[16];
+    int p = blockIdx.x * kBlock + threadIdx.x;
+    double cost = 0.0, gmax = 0.0;
+    if (p < d.n_pts) {
+        double4 X = d.X[p];
+        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
+        for (int j = j0; j < j1; ++j) {
+            Cam k = load_cam(d.cams, d.pm_cam[j]);
+            Seed s = project_seed(k, X.x, X.y, X.z);
+            double2 uv = d.pm_uv[j];
+            double ru, rv;
+            residual(s, d.K, uv.x, uv.y, ru, rv);
+            d.pm_sx[j] = s.x; d.pm_sy[j] = s.y; d.pm_siz[j] = s.iz;
+            d.pm_ru[j] = ru; d.pm_rv[j] = rv;
+            double a[3], b[3];
+            jac_pt(s, d.K, k.q, a, b);
+            V[0] += a[0] * a[0] + b[0] * b[0];
+            V[1] += a[0] * a[1] + b[0] * b[1];
+            V[2] += a[0] * a[2] + b[0] * b[2];
+            V[3] += a[1] * a[1] + b[1] * b[1];
+            V[4] += a[1] * a[2] + b[1] * b[2];
+            V[5] += a[2] * a[2] + b[2] * b[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g[i] += a[i] * ru + b[i] * rv;
+            cost += ru * ru + rv * rv;
+        }
+        double* Vo = d.V + 6 * (size_t)p;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Vo[i] = V[i];
+        double* go = d.gp + 4 * (size_t)p;
+        go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; go[3] = 0.0;
+        gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    }
+    double c = block_sum(cost, red);
+    double m = block_max(gmax, red);
+    if (threadIdx.x == 0) { put_partial(d, SLOT_COST, c); put_partial(d, SLOT_GMAX_PT, m); }
+}
+
+// Linearisation, camera-major half: seeds per observation (camera-major copy) and the chunk
+// partials of U_c (21 packed upper) and g_c (6).
+__global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_chunks) return;
+    const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
+    const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
+    const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
+    Cam cam = load_cam(d.cams, c);
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        double4 X = d.X[d.cm_pt[k]];
+        Seed s = project_seed(cam, X.x, X.y, X.z);
+        double2 uv = d.cm_uv[k];
+        double ru, rv;
+        residual(s, d.K, uv.x, uv.y, ru, rv);
+        d.cm_sx[k] = s.x; d.cm_sy[k] = s.y; d.cm_siz[k] = s.iz;
+        double jc[12];
+        jac_cam(s, d.K, jc);
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) acc[n++] += jc[i] * jc[j] + jc[6 + i] * jc[6 + j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += jc[i] * ru + jc[6 + i] * rv;
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        double* o = d.chunk_part + 27 * (size_t)q;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) o[i] = acc[i];
+    }
+}
+
+// out[c][v] = sum over the chunks of camera c of chunk_part[q][v], fixed order.
+__global__ __launch_bounds__(kBlock) void k_chunk_reduce(Dev d, int nvals, double* __restrict__ out) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.n_cam * nvals) return;
+    int c = i / nvals, v = i - c * nvals;
+    double s = 0.0;
+    for (int q = d.cam_chunk_ptr[c]; q < d.cam_chunk_ptr[c + 1]; ++q)
+        s += d.chunk_part[(size_t)q * nvals + v];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Damping, per point: Vinv = (V + lambda * clamp(diag V))^-1 and s0 = Vinv g_p.
+__global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
+    int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= d.n_pts) return;
+    const double* Vi = d.V + 6 * (size_t)p;
+    double V[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) V[i] = Vi[i];
+    V[0] += lambda * fmin(fmax(V[0], 1e-6), 1e32);
+    V[3] += lambda * fmin(fmax(V[3], 1e-6), 1e32);
+    V[5] += lambda * fmin(fmax(V[5], 1e-6), 1e32);
+    double inv[6];
+    spd3_inverse(V, inv);
+    double* o = d.Vinv + 6 * (size_t)p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = inv[i];
+    const double* g = d.gp + 4 * (size_t)p;
+    double4 s;
+    s.x = inv[0] * g[0] + inv[1] * g[1] + inv[2] * g[2];
+    s.y = inv[1] * g[0] + inv[3] * g[1] + inv[4] * g[2];
+    s.z = inv[2] * g[0] + inv[4] * g[1] + inv[5] * g[2];
+    s.w = 0.0;
+    d.s0[p] = s;
+}
+
+// Camera-major: chunk partials of T_c = sum W Vinv W' (21 packed upper) and sum W s0 (6),
+// W = Jc' Jp (6x3).
+__global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_chunks) return;
+    const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
+    const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
+    const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
+    Cam cam = load_cam(d.cams, c);
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        const int p = d.cm_pt[k];
+        Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
+        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
+        double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        double4 s0 = d.s0[p];
+        double jc[12], a[3], b[3];
+        jac_cam(s, d.K, jc);
+        jac_pt(s, d.K, cam.q, a, b);
+        // W (6x3) and M = W Vinv (6x3)
+        double W[6][3], M[6][3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) W[i][kk] = jc[i] * a[kk] + jc[6 + i] * b[kk];
+            M[i][0] = W[i][0] * v01.x + W[i][1] * v01.y + W[i][2] * v23.x;
+            M[i][1] = W[i][0] * v01.y + W[i][1] * v23.y + W[i][2] * v45.x;
+            M[i][2] = W[i][0] * v23.x + W[i][1] * v45.x + W[i][2] * v45.y;
+        }
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j)
+                acc[n++] += M[i][0] * W[j][0] + M[i][1] * W[j][1] + M[i][2] * W[j][2];
+        // W * (Vinv g_p) : the right-hand-side contribution
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += W[i][0] * s0.x + W[i][1] * s0.y + W[i][2] * s0.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        double* o = d.chunk_part + 27 * (size_t)q;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) o[i] = acc[i];
+    }
+}
+
+// Per camera: Minv = (U + lambda D - T)^-1, rhs = -g_c + T[21..26]; gradient max.
+__global__ __launch_bounds__(kBlock) void k_precond(Dev d, double lambda) {
+    __shared__ double red[16];
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    double gmax = 0.0;
+    if (c < d.n_cam) {
+        const double* U = d.UG + 27 * (size_t)c;
+        const double* T = d.T + 27 * (size_t)c;
+        double A[6][6], Ai[6][6], Ud[6];
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                double v = U[n] - T[n];
+                if (i == j) { Ud[i] = U[n] + lambda * fmin(fmax(U[n], 1e-6), 1e32); v = Ud[i] - T[n]; }
+                A[i][j] = v; A[j][i] = v;
+                ++n;
+            }
+        bool ok = spd6_inverse(A, Ai);
+        double* o = d.Minv + 36 * (size_t)c;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) o[6 * i + j] = Ai[i][j];
+        } else {   // fall back to the damped diagonal of U
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) o[6 * i + j] = (i == j) ? 1.0 / Ud[i] : 0.0;
+        }
+        const double* g = d.UG + 27 * (size_t)c + 21;
+        double* r = d.rhs + 6 * (size_t)c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            r[i] = -g[i] + T[21 + i];
+            gmax = fmax(gmax, fabs(g[i]));
+        }
+    }
+    double m = block_max(gmax, red);
+    if (threadIdx.x == 0) put_partial(d, SLOT_GMAX_CAM, m);
+}
+
+// ------------------------------------------------------------------------------------------
+// Schur matvec, point-major half: s_p = Vinv_p * sum_o Jp' (Jc x_c).
+__global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restrict__ x, int check_done) {
+    if (check_done && d.pcg->done) return;
+    int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= d.n_pts) return;
+    double t[3] = {0, 0, 0};
+    int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
+    for (int j = j0; j < j1; ++j) {
+        const int c = d.pm_cam[j];
+        Seed s; s.x = d.pm_sx[j]; s.y = d.pm_sy[j]; s.iz = d.pm_siz[j];
+        const double2* xc = reinterpret_cast<const double2*>(x + 6 * (size_t)c);
+        double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
+        double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+        double w0, w1;
+        jc_times(s, d.K, dd, w0, w1);
+        const double2* cq = d.cams + 6 * (size_t)c;
+        double2 q01 = cq[0], q23 = cq[1], q45 = cq[2], q67 = cq[3], q8 = cq[4];
+        double Q[9] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y, q8.x};
+        jpT_times_acc(s, d.K, Q, w0, w1, t);
+    }
+    const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
+    double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+    double4 s;
+    s.x = v01.x * t[0] + v01.y * t[1] + v23.x * t[2];
+    s.y = v01.y * t[0] + v23.y * t[1] + v45.x * t[2];
+    s.z = v23.x * t[0] + v45.x * t[1] + v45.y * t[2];
+    s.w = 0.0;
+    d.s[p] = s;
+}
+
+// Schur matvec, camera-major half: chunk partials of sum_o Jc' (Jp s_p)  (6 values).
+__global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, int check_done) {
+    if (check_done && d.pcg->done) return;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_chunks) return;
+    const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
+    const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
+    const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
+    Cam cam = load_cam(d.cams, c);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = k0 + lane; k < k1; k += 64) {
+        Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
+        double4 sp = d.s[d.cm_pt[k]];
+        double dd[3] = {sp.x, sp.y, sp.z};
+        double w0, w1;
+        jp_times(s, d.K, cam.q, dd, w0, w1);
+        jcT_times_acc(s, d.K, w0, w1, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        double* o = d.chunk_part + 6 * (size_t)q;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = acc[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PCG on the reduced camera system, vectors [n_cam][6], one thread per camera.
+// PcgState is double-buffered: a kernel reads pcg[cur] and only k_pcg_dir writes pcg[cur^1].
+
+__device__ __forceinline__ void ustar_times(const double* U, double lambda, const double* x, double* y) {
+    double A[6][6];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) { A[i][j] = U[n]; A[j][i] = U[n]; ++n; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) A[i][i] += lambda * fmin(fmax(A[i][i], 1e-6), 1e32);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v += A[i][j] * x[j];
+        y[i] = v;
+    }
+}
+
+__device__ __forceinline__ void mat6_times(const double* M, const double* x, double* y) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v += M[6 * i + j] * x[j];
+        y[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d) {
+    __shared__ double red[16];
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    double dot = 0.0;
+    if (c < d.n_cam) {
+        const double* b = d.rhs + 6 * (size_t)c;
+        double r[6], z[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = b[i];
+        mat6_times(d.Minv + 36 * (size_t)c, r, z);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            d.px[6 * (size_t)c + i] = 0.0;
+            d.pr[6 * (size_t)c + i] = r[i];
+            d.pz[6 * (size_t)c + i] = z[i];
+            d.pp[6 * (size_t)c + i] = z[i];
+            dot += r[i] * z[i];
+        }
+    }
+    double s = block_sum(dot, red);
+    if (threadIdx.x == 0) d.dot_part[gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void k_pcg_state_init(Dev d, int nb, double tol, int max_iter) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double rz = 0.0;
+    for (int i = 0; i < nb; ++i) rz += d.dot_part[nb + i];
+    PcgState st;
+    st.rz = rz; st.rz0 = rz; st.tol2 = tol * tol; st.iter = 0; st.max_iter = max_iter;
+    st.done = !(rz > 0.0);   // zero (or NaN) right-hand side: nothing to iterate on
+    st.pad = 0;
+    d.pcg[0] = st;
+    d.pcg[1] = st;
+}
+
+// q = U* p - qS ; block partials of p'q.
+__global__ __launch_bounds__(kBlock) void k_pcg_q(Dev d, double lambda, int cur) {
+    __shared__ double red[16];
+    if (d.pcg[cur].done) return;
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    double dot = 0.0;
+    if (c < d.n_cam) {
+        double p[6], q[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p[i] = d.pp[6 * (size_t)c + i];
+        ustar_times(d.UG + 27 * (size_t)c, lambda, p, q);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            q[i] -= d.qS[6 * (size_t)c + i];
+            d.pq[6 * (size_t)c + i] = q[i];
+            dot += p[i] * q[i];
+        }
+    }
+    double s = block_sum(dot, red);
+    if (threadIdx.x == 0) d.dot_part[blockIdx.x] = s;
+}
+
+// alpha = rz / p'q ; x += alpha p ; r -= alpha q ; z = Minv r ; block partials of r'z.
+__global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur) {
+    __shared__ double red[16];
+    if (d.pcg[cur].done) return;
+    const int nb = gridDim.x;
+    double pq = 0.0;
+    for (int i = 0; i < nb; ++i) pq += d.dot_part[i];
+    const double alpha = d.pcg[cur].rz / pq;
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    double dot = 0.0;
+    if (c < d.n_cam) {
+        double r[6], z[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            size_t o = 6 * (size_t)c + i;
+            d.px[o] += alpha * d.pp[o];
+            r[i] = d.pr[o] - alpha * d.pq[o];
+            d.pr[o] = r[i];
+        }
+        mat6_times(d.Minv + 36 * (size_t)c, r, z);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { d.pz[6 * (size_t)c + i] = z[i]; dot += r[i] * z[i]; }
+    }
+    double s = block_sum(dot, red);
+    if (threadIdx.x == 0) d.dot_part[nb + blockIdx.x] = s;
+}
+
+// beta = rz_new / rz ; p = z + beta p ; block 0 writes the next state.
+__global__ __launch_bounds__(kBlock) void k_pcg_dir(Dev d, int cur) {
+    const PcgState st = d.pcg[cur];
+    if (st.done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg[cur ^ 1] = st;
+        return;
+    }
+    const int nb = gridDim.x;
+    double rz_new = 0.0;
+    for (int i = 0; i < nb; ++i) rz_new += d.dot_part[nb + i];
+    const double beta = rz_new / st.rz;
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c < d.n_cam) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            size_t o = 6 * (size_t)c + i;
+            d.pp[o] = d.pz[o] + beta * d.pp[o];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PcgState nx = st;
+        nx.rz = rz_new;
+        nx.iter = st.iter + 1;
+        nx.done = (!(rz_new > nx.tol2 * nx.rz0)) || (nx.iter >= nx.max_iter);
+        d.pcg[cur ^ 1] = nx;
+    }
+}
+
+// y = U* x - qS  (diagnostic: one application of the reduced operator).
+__global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __restrict__ x,
+                                                        double lambda, double* __restrict__ y) {
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= d.n_cam) return;
+    double p[6], q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p[i] = x[6 * (size_t)c + i];
+    ustar_times(d.UG + 27 * (size_t)c, lambda, p, q);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[6 * (size_t)c + i] = q[i] - d.qS[6 * (size_t)c + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Back-substitution per point: dp = -Vinv (g_p + sum Jp' Jc dc); X_trial = X + dp; the cost of
+// the linear model at the step; |dp|^2 and |X|^2.
+__global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
+                                                    double* __restrict__ dp_out) {
+    __shared__ double red[16];
+    int p = blockIdx.x * kBlock + threadIdx.x;
+    double model = 0.0, step2 = 0.0, x2 = 0.0;
+    if (p < d.n_pts) {
+        double t[3] = {0, 0, 0};
+        int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
+        for (int j = j0; j < j1; ++j) {
+            const int c = d.pm_cam[j];
+            Seed s; s.x = d.pm_sx[j]; s.y = d.pm_sy[j]; s.iz = d.pm_siz[j];
+            const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)c);
+            double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
+            double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+            double w0, w1;
+            jc_times(s, d.K, dd, w0, w1);
+            Cam k = load_cam(d.cams, c);
+            jpT_times_acc(s, d.K, k.q, w0, w1, t);
+        }
+        const double* g = d.gp + 4 * (size_t)p;
+        t[0] += g[0]; t[1] += g[1]; t[2] += g[2];
+        const double* vi = d.Vinv + 6 * (size_t)p;
+        double dp[3];
+        dp[0] = -(vi[0] * t[0] + vi[1] * t[1] + vi[2] * t[2]);
+        dp[1] = -(vi[1] * t[0] + vi[3] * t[1] + vi[4] * t[2]);
+        dp[2] = -(vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
+        double4 X = d.X[p];
+        double4 Xn = X;
+        Xn.x += dp[0]; Xn.y += dp[1]; Xn.z += dp[2];
+        d.X_trial[p] = Xn;
+        if (dp_out) { dp_out[3 * (size_t)p] = dp[0]; dp_out[3 * (size_t)p + 1] = dp[1]; dp_out[3 * (size_t)p + 2] = dp[2]; }
+        step2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+        x2 = X.x * X.x + X.y * X.y + X.z * X.z;
+        for (int j = j0; j < j1; ++j) {
+            const int c = d.pm_cam[j];
+            Seed s; s.x = d.pm_sx[j]; s.y = d.pm_sy[j]; s.iz = d.pm_siz[j];
+            const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)c);
+            double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
+            double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+            double w0, w1, u0, u1;
+            jc_times(s, d.K, dd, w0, w1);
+            Cam k = load_cam(d.cams, c);
+            jp_times(s, d.K, k.q, dp, u0, u1);
+            double l0 = d.pm_ru[j] + w0 + u0, l1 = d.pm_rv[j] + w1 + u1;
+            model += l0 * l0 + l1 * l1;
+        }
+    }
+    double a = block_sum(model, red);
+    double b = block_sum(step2, red);
+    double c2 = block_sum(x2, red);
+    if (threadIdx.x == 0) {
+        put_partial(d, SLOT_MODEL, a);
+        put_partial(d, SLOT_STEP2_PT, b);
+        put_partial(d, SLOT_X2_PT, c2);
+    }
+}
+
+// Camera retraction: Q' = exp([dw]x) Q, t' = exp([dw]x) t + dt.
+__global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __restrict__ dc) {
+    __shared__ double red[16];
+    int c = blockIdx.x * kBlock + threadIdx.x;
+    double step2 = 0.0, x2 = 0.0;
+    if (c < d.n_cam) {
+        Cam k = load_cam(d.cams, c);
+        double w[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { w[i] = dc[6 * (size_t)c + i]; step2 += w[i] * w[i]; }
+        double E[9];
+        so3_exp(w, E);
+        double o[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                o[3 * i + j] = E[3 * i] * k.q[j] + E[3 * i + 1] * k.q[3 + j] + E[3 * i + 2] * k.q[6 + j];
+            o[9 + i] = E[3 * i] * k.t[0] + E[3 * i + 1] * k.t[1] + E[3 * i + 2] * k.t[2] + w[3 + i];
+        }
+        double2* dst = d.cams_trial + 6 * (size_t)c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
+        x2 = 3.0 + k.t[0] * k.t[0] + k.t[1] * k.t[1] + k.t[2] * k.t[2];
+    }
+    double a = block_sum(step2, red);
+    double b = block_sum(x2, red);
+    if (threadIdx.x == 0) { put_partial(d, SLOT_STEP2_CAM, a); put_partial(d, SLOT_X2_CAM, b); }
+}
+
+// Cost at the trial point (cams_trial, X_trial).
+__global__ __launch_bounds__(kBlock) void k_cost_pm(Dev d) {
+    __shared__ double red[16];
+    int p = blockIdx.x * kBlock + threadIdx.x;
+    double cost = 0.0, bad = 0.0;
+    if (p < d.n_pts) {
+        double4 X = d.X_trial[p];
+        int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
+        for (int j = j0; j < j1; ++j) {
+            Cam k = load_cam(d.cams_trial, d.pm_cam[j]);
+            Seed s = project_seed(k, X.x, X.y, X.z);
+            double2 uv = d.pm_uv[j];
+            double ru, rv;
+            residual(s, d.K, uv.x, uv.y, ru, rv);
+            double e = ru * ru + rv * rv;
+            if (isfinite(e)) cost += e; else bad += 1.0;
+        }
+    }
+    double a = block_sum(cost, red);
+    double b = block_sum(bad, red);
+    if (threadIdx.x == 0) { put_partial(d, SLOT_TRIAL, a); put_partial(d, SLOT_NONFINITE, b); }
+}
+
+// scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per slot.
+__global__ __launch_bounds__(kBlock) void k_scal_finalize(Dev d, int first_slot, int nblocks, unsigned max_mask) {
+    __shared__ double red[16];
+    const int slot = first_slot + blockIdx.x;
+    const bool is_max = (max_mask >> blockIdx.x) & 1u;
+    const double* part = d.scal_part + (size_t)slot * kMaxScalBlocks;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) v = is_max ? fmax(v, part[i]) : v + part[i];
+    double r = is_max ? block_max(v, red) : block_sum(v, red);
+    if (threadIdx.x == 0) d.scalars[slot] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
+static int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
+static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kBlock / 64); }
+
+void launch_residuals(const Dev& d, double* out, hipStream_t st) {
+    if (d.n_obs == 0) return;
+    hipLaunchKernelGGL(k_residuals, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, out);
+}
+void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st) {
+    if (d.n_obs == 0) return;
+    hipLaunchKernelGGL(k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, jc, jp);
+}
+void launch_lin_pm(const Dev& d, hipStream_t st) {
+    if (d.n_pts == 0) return;
+    hipLaunchKernelGGL(k_lin_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(kBlock), 0, st, d, (int)SLOT_COST, scal_blocks_pt(d), 2u);
+}
+void launch_lin_cm(const Dev& d, hipStream_t st) {
+    if (d.n_chunks == 0) return;
+    hipLaunchKernelGGL(k_lin_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d);
+}
+void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_chunk_reduce, dim3(cdiv(d.n_cam * nvals, kBlock)), dim3(kBlock), 0, st, d, nvals, out);
+}
+void launch_damp_pm(const Dev& d, double lambda, hipStream_t st) {
+    if (d.n_pts == 0) return;
+    hipLaunchKernelGGL(k_damp_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d, lambda);
+}
+void launch_sdiag_cm(const Dev& d, hipStream_t st) {
+    if (d.n_chunks == 0) return;
+    hipLaunchKernelGGL(k_sdiag_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d);
+}
+void launch_precond(const Dev& d, double lambda, hipStream_t st) {
+    hipLaunchKernelGGL(k_precond, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(kBlock), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
+}
+void launch_spmv_pm(const Dev& d, const double* x, bool check_done, hipStream_t st) {
+    if (d.n_pts == 0) return;
+    hipLaunchKernelGGL(k_spmv_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d, x, (int)check_done);
+}
+void launch_spmv_cm(const Dev& d, bool check_done, hipStream_t st) {
+    if (d.n_chunks == 0) return;
+    hipLaunchKernelGGL(k_spmv_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d, (int)check_done);
+}
+void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
+    hipLaunchKernelGGL(k_pcg_init, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_pcg_state_init, dim3(1), dim3(64), 0, st, d, blocks_cam(d), tol, max_iter);
+}
+void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st) {
+    hipLaunchKernelGGL(k_pcg_q, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
+}
+void launch_pcg_update(const Dev& d, int cur, hipStream_t st) {
+    hipLaunchKernelGGL(k_pcg_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
+}
+void launch_pcg_dir(const Dev& d, int cur, hipStream_t st) {
+    hipLaunchKernelGGL(k_pcg_dir, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
+}
+void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st) {
+    hipLaunchKernelGGL(k_schur_apply, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, x, lambda, y);
+}
+void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st) {
+    if (d.n_pts == 0) return;
+    hipLaunchKernelGGL(k_back_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d, dc, dp_out);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(3), dim3(kBlock), 0, st, d, (int)SLOT_MODEL, scal_blocks_pt(d), 0u);
+}
+void launch_cam_update(const Dev& d, const double* dc, hipStream_t st) {
+    hipLaunchKernelGGL(k_cam_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, dc);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(kBlock), 0, st, d, (int)SLOT_STEP2_CAM, blocks_cam(d), 0u);
+}
+void launch_cost_pm(const Dev& d, hipStream_t st) {
+    if (d.n_pts == 0) return;
+    hipLaunchKernelGGL(k_cost_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(kBlock), 0, st, d, (int)SLOT_TRIAL, scal_blocks_pt(d), 0u);
+}
+
+}  // namespace sfmba

@@ -1,0 +1,262 @@
+"""ctypes binding of libsfmba.so (declared in include/sfmba.h).
+
+`Engine` owns one `sfmba_handle`, i.e. one bundle-adjustment problem resident on one MI355X.
+Every method is a thin call through the C ABI; there is no CPU fallback: if the shared
+library cannot be loaded, or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmba.so")
+
+# every symbol include/sfmba.h declares
+EXPORTS = (
+    "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error",
+    "sfmba_set_problem", "sfmba_set_params", "sfmba_residuals", "sfmba_jacobian_blocks",
+    "sfmba_solve", "sfmba_get_params", "sfmba_linearize", "sfmba_get_blocks",
+    "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_solve_step",
+    "sfmba_comm_unique_id", "sfmba_comm_init",
+)
+
+SOLVER_AUTO, SOLVER_PCG, SOLVER_DENSE = 0, 1, 2
+
+TERMINATION_MESSAGES = {   # scipy/optimize/_lsq/least_squares.py:18-25
+    -1: "Improper input parameters status returned from `leastsq`",
+    0: "The maximum number of function evaluations is exceeded.",
+    1: "`gtol` termination condition is satisfied.",
+    2: "`ftol` termination condition is satisfied.",
+    3: "`xtol` termination condition is satisfied.",
+    4: "Both `ftol` and `xtol` termination conditions are satisfied.",
+}
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
+        ("max_nfev", C.c_int32), ("max_iterations", C.c_int32),
+        ("initial_lambda", C.c_double), ("pcg_rtol", C.c_double),
+        ("pcg_max_iter", C.c_int32), ("linear_solver", C.c_int32),
+        ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
+        ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("iterations", C.c_int32), ("accepted", C.c_int32),
+        ("nfev", C.c_int32), ("njev", C.c_int32), ("pcg_iterations", C.c_int32),
+        ("linear_solver", C.c_int32), ("reserved", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("optimality", C.c_double), ("solve_seconds", C.c_double),
+        ("ms_linearize", C.c_double), ("n_linearize", C.c_int64),
+        ("ms_damp", C.c_double), ("n_damp", C.c_int64),
+        ("ms_spmv_pm", C.c_double), ("n_spmv_pm", C.c_int64),
+        ("ms_spmv_cm", C.c_double), ("n_spmv_cm", C.c_int64),
+        ("ms_pcg_vec", C.c_double), ("n_pcg_vec", C.c_int64),
+        ("ms_back", C.c_double), ("n_back", C.c_int64),
+        ("ms_cost", C.c_double), ("n_cost", C.c_int64),
+        ("ms_dense", C.c_double), ("n_dense", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libsfmba error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libsfmba.so and declare its prototypes.  Raises OSError when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    lib = C.CDLL(path or _LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p
+    lib.sfmba_default_options.argtypes = [C.POINTER(Options)]
+    lib.sfmba_default_options.restype = None
+    lib.sfmba_create.argtypes = [C.POINTER(Options), C.POINTER(vp)]
+    lib.sfmba_destroy.argtypes = [vp]
+    lib.sfmba_last_error.argtypes = [vp]
+    lib.sfmba_last_error.restype = C.c_char_p
+    lib.sfmba_set_problem.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp, dp, ip, ip, dp, dp]
+    lib.sfmba_set_params.argtypes = [vp, dp, dp]
+    lib.sfmba_residuals.argtypes = [vp, dp]
+    lib.sfmba_jacobian_blocks.argtypes = [vp, dp, dp]
+    lib.sfmba_solve.argtypes = [vp, C.POINTER(Stats)]
+    lib.sfmba_get_params.argtypes = [vp, dp, dp]
+    lib.sfmba_linearize.argtypes = [vp, C.c_double]
+    lib.sfmba_get_blocks.argtypes = [vp, dp, dp, dp, dp]
+    lib.sfmba_schur_matvec.argtypes = [vp, dp, dp]
+    lib.sfmba_get_reduced.argtypes = [vp, dp, dp]
+    lib.sfmba_solve_step.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
+    lib.sfmba_comm_unique_id.argtypes = [vp]
+    lib.sfmba_comm_init.argtypes = [vp, vp]
+    for name in EXPORTS:
+        if name not in ("sfmba_default_options", "sfmba_last_error"):
+            getattr(lib, name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def default_options(**kw):
+    lib = load_library()
+    o = Options()
+    lib.sfmba_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+class Engine:
+    """One problem on one GPU.  Array arguments use the reference's layouts
+    (/root/reference/bundle_adjustment.py:94-126)."""
+
+    def __init__(self, **options):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.options = default_options(**options)
+        rc = self._lib.sfmba_create(C.byref(self.options), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise EngineError(rc, {-6: "no usable GPU (libsfmba needs a gfx950 device)"}.get(rc, "sfmba_create failed"))
+        self.n_cameras = self.n_points = self.n_obs = 0
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.sfmba_last_error(self._h).decode("utf-8", "replace")
+            if rc == -2:
+                raise IndexError(msg)          # NumPy's behaviour at bundle_adjustment.py:49
+            if rc == -3:
+                raise ValueError(msg)          # SciPy's behaviour, least_squares.py:844-845
+            raise EngineError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sfmba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- problem
+    def set_problem(self, camera_params, points_3d, camera_indices, point_indices, points_2d, K):
+        cp, pts = _f64(camera_params), _f64(points_3d)
+        ci, pi, uv, K = _i64(camera_indices), _i64(point_indices), _f64(points_2d), _f64(K)
+        if cp.ndim != 2 or cp.shape[1] != 12:
+            raise ValueError("camera_params must be (n_cameras, 12)")
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points_3d must be (n_points, 3)")
+        if ci.shape != pi.shape or ci.ndim != 1 or uv.shape != (ci.size, 2):
+            raise ValueError("camera_indices, point_indices (n_obs,) and points_2d (n_obs, 2) disagree")
+        if K.shape != (3, 3):
+            raise ValueError("K must be 3x3")
+        self.n_cameras, self.n_points, self.n_obs = cp.shape[0], pts.shape[0], ci.size
+        ipp = C.POINTER(C.c_int64)
+        self._check(self._lib.sfmba_set_problem(
+            self._h, cp.shape[0], pts.shape[0], ci.size, _dp(cp), _dp(pts),
+            ci.ctypes.data_as(ipp), pi.ctypes.data_as(ipp), _dp(uv), _dp(K)))
+
+    def set_params(self, camera_params, points_3d):
+        cp, pts = _f64(camera_params), _f64(points_3d)
+        if cp.shape != (self.n_cameras, 12) or pts.shape != (self.n_points, 3):
+            raise ValueError("parameter shapes do not match the loaded problem")
+        self._check(self._lib.sfmba_set_params(self._h, _dp(cp), _dp(pts)))
+
+    def get_params(self):
+        cp = np.empty((self.n_cameras, 12))
+        pts = np.zeros((self.n_points, 3))
+        self._check(self._lib.sfmba_get_params(self._h, _dp(cp), _dp(pts)))
+        return cp, pts
+
+    # -- evaluation
+    def residuals(self):
+        out = np.zeros(2 * self.n_obs)
+        self._check(self._lib.sfmba_residuals(self._h, _dp(out)))
+        return out
+
+    def jacobian_blocks(self):
+        jc = np.zeros((self.n_obs, 2, 6))
+        jp = np.zeros((self.n_obs, 2, 3))
+        self._check(self._lib.sfmba_jacobian_blocks(self._h, _dp(jc), _dp(jp)))
+        return jc, jp
+
+    def solve(self):
+        st = Stats()
+        self._check(self._lib.sfmba_solve(self._h, C.byref(st)))
+        return st
+
+    # -- diagnostics
+    def linearize(self, lam):
+        self._check(self._lib.sfmba_linearize(self._h, float(lam)))
+
+    def get_blocks(self):
+        U = np.zeros((self.n_cameras, 6, 6)); gc = np.zeros((self.n_cameras, 6))
+        V = np.zeros((self.n_points, 3, 3)); gp = np.zeros((self.n_points, 3))
+        self._check(self._lib.sfmba_get_blocks(self._h, _dp(U), _dp(gc), _dp(V), _dp(gp)))
+        return U, gc, V, gp
+
+    def schur_matvec(self, x):
+        x = _f64(x).reshape(self.n_cameras, 6)
+        y = np.empty_like(x)
+        self._check(self._lib.sfmba_schur_matvec(self._h, _dp(x), _dp(y)))
+        return y
+
+    def get_reduced(self):
+        rhs = np.empty((self.n_cameras, 6)); Minv = np.empty((self.n_cameras, 6, 6))
+        self._check(self._lib.sfmba_get_reduced(self._h, _dp(rhs), _dp(Minv)))
+        return rhs, Minv
+
+    def solve_step(self):
+        dc = np.zeros((self.n_cameras, 6)); dp = np.zeros((self.n_points, 3))
+        it = C.c_int32(0)
+        self._check(self._lib.sfmba_solve_step(self._h, _dp(dc), _dp(dp), C.byref(it)))
+        return dc, dp, it.value
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.sfmba_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(rc, "could not obtain an RCCL unique id")
+        return buf.raw
+
+    def comm_init(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.sfmba_comm_init(self._h, buf))
