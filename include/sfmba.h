@@ -122,6 +122,10 @@ int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int6
  * re-run a solve from the same start, and to evaluate fun() at another x). */
 int sfmba_set_params(sfmba_handle* h, const double* camera_params, const double* points_3d);
 
+/* Restore the estimate last given to sfmba_set_problem / sfmba_set_params from its copy in
+ * device memory (no host transfer): lets a caller repeat a solve from the same start. */
+int sfmba_reset_params(sfmba_handle* h);
+
 /* fun(params) of bundle_adjustment.py:34-50 at the current estimate: out has 2*n_obs entries,
  * [du0, dv0, du1, dv1, ...] in the caller's observation order.  On a partitioned handle only
  * the entries of locally owned observations are written (the rest are left untouched). */

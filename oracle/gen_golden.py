@@ -1,0 +1,134 @@
+"""Generates tests/golden/*.npz: inputs in the reference's optimize_data.npz layout
+(/root/reference/bundle_adjustment.py:125-126) and the outputs of the CPU oracle on them.
+TEST INFRASTRUCTURE; run in the build container:  python -m oracle.gen_golden
+
+Each file holds camera_params, points_3d, camera_indices, point_indices, points_2d, K and
+  f0                      oracle fun(x0)                              (residual parity, 1e-10)
+  jac_data/indices/indptr SciPy approx_derivative(fun, x0, '2-point', sparsity=A) as CSR
+                          (the Jacobian the reference hands to TRF; parity 1e-5)
+  ref_*                   scipy least_squares with the reference kwargs (cost, status, nfev,
+                          njev, optimality)
+  tight_cost              the same solver run to (near) stationarity      (parity 1e-6)
+The reference holds no fixtures of its own for this path, so these vectors pin the engine to
+the oracle, and the oracle's projection model stays "parity unpinned" (see ba_oracle.py).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+from scipy.optimize._numdiff import approx_derivative
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ba_oracle as o  # noqa: E402
+from structure_from_motion_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def fd_jacobian(prob):
+    x0, args = o.pack(prob)
+    A = o.bundle_adjustment_sparsity(prob["n_cameras"], prob["n_points"],
+                                     prob["camera_indices"], prob["point_indices"])
+    f0 = o.fun(x0, *args)
+    J = approx_derivative(o.fun, x0, method="2-point", f0=f0, sparsity=A, args=args).tocsr()
+    J.sort_indices()
+    return J
+
+
+def record(name, prob, jac=True, solve=True, tight=True, tight_nfev=200):
+    x0, args = o.pack(prob)
+    out = {k: prob[k] for k in ("camera_params", "points_3d", "camera_indices",
+                                "point_indices", "points_2d", "K")}
+    out["f0"] = o.fun(x0, *args)
+    if jac:
+        J = fd_jacobian(prob)
+        out["jac_data"], out["jac_indices"], out["jac_indptr"] = J.data, J.indices, J.indptr
+    if solve:
+        r = o.solve_reference(prob)
+        out["ref_cost"] = r["cost"]; out["ref_status"] = r["status"]; out["ref_nfev"] = r["nfev"]
+        out["ref_njev"] = r["njev"]; out["ref_optimality"] = r["optimality"]
+        out["ref_initial_cost"] = r["initial_cost"]
+        out["ref_poses"] = r["poses"]; out["ref_points_3d"] = r["points_3d"]
+    if tight:
+        r = o.solve_tight(prob, max_nfev=tight_nfev)
+        out["tight_cost"] = r["cost"]; out["tight_optimality"] = r["optimality"]
+        out["tight_nfev"] = r["nfev"]
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: n_obs={prob['camera_indices'].size} cost0={0.5 * out['f0'] @ out['f0']:.6e} "
+          + (f"ref={out['ref_cost']:.9e} status={out['ref_status']} " if solve else "")
+          + (f"tight={out['tight_cost']:.9e} opt={out['tight_optimality']:.2e}" if tight else ""))
+
+
+def edge_problem():
+    """Degenerate geometry the reference tolerates: a point exactly on a camera's principal plane
+    (Z == 0, cv2 treats 1/Z as 1), a point behind a camera, a camera with one observation,
+    a duplicated (camera, point) pair and an unobserved point."""
+    rng = np.random.default_rng(7)
+    p = syn.make_problem(5, 12, 30, seed=7, window=5)
+    cp = p["camera_params"].copy()
+    X = p["points_3d"].copy()
+    ci = p["camera_indices"].copy()
+    pi = p["point_indices"].copy()
+    uv = p["points_2d"].copy()
+    # camera 4 keeps a single observation
+    keep = (ci != 4)
+    first4 = np.flatnonzero(ci == 4)[:1]
+    keep[first4] = True
+    ci, pi, uv = ci[keep], pi[keep], uv[keep]
+    # duplicate one (camera, point) pair
+    ci = np.r_[ci, ci[3]]; pi = np.r_[pi, pi[3]]; uv = np.vstack([uv, uv[3] + 0.25])
+    # an unobserved extra point
+    X = np.vstack([X, rng.uniform(-1, 1, (1, 3))])
+    # point 0 exactly on the principal plane of camera 0: identity rotation and t2 = -X2 make
+    # Y2 = 1*X2 + t2 == 0 in every evaluation order
+    j = int(np.flatnonzero(pi == 0)[0])
+    ci[j] = 0
+    cp[0, :9] = np.eye(3).ravel()
+    cp[0, 9:12] = [0.25, -0.5, -X[0, 2]]
+    # point 1 behind its first camera
+    j = int(np.flatnonzero(pi == 1)[0]); c1 = int(ci[j])
+    Q1 = o.camera_rotations(cp[c1:c1 + 1])[0]
+    X[1] = Q1.T @ (np.array([0.1, 0.1, -2.0]) - cp[c1, 9:12])
+    return {"camera_params": cp, "points_3d": X, "camera_indices": ci, "point_indices": pi,
+            "points_2d": uv, "K": p["K"], "n_cameras": 5, "n_points": X.shape[0], "n_obs": ci.size}
+
+
+def nonortho_problem():
+    """Rotation blocks that are not orthonormal (noise 1e-3, one scaled by 1.7, one exactly the
+    identity): pins the polar-projection semantics of the 12-number camera."""
+    p = syn.make_problem(6, 60, 200, seed=11, window=6)
+    rng = np.random.default_rng(11)
+    cp = p["camera_params"].copy()
+    # move the gauge so that camera 0 is exactly [I | 0], as the reference's first view is
+    R0 = o.camera_rotations(cp[0:1])[0]
+    t0 = cp[0, 9:12].copy()
+    R = o.camera_rotations(cp)
+    Rn = np.einsum("nij,kj->nik", R, R0)                 # R R0^T
+    tn = cp[:, 9:12] - np.einsum("nij,j->ni", Rn, t0)
+    p["points_3d"] = p["points_3d"] @ R0.T + t0
+    cp = np.hstack([Rn.reshape(6, 9), tn])
+    cp[1:, :9] += rng.normal(0, 1e-3, (5, 9))
+    cp[2, :9] *= 1.7
+    cp[0, :9] = np.eye(3).ravel()
+    cp[0, 9:12] = 0.0
+    p["camera_params"] = cp
+    return p
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    record("tiny_4_50_150", syn.make_problem(4, 50, 150, seed=1, window=4))
+    record("rho2_11_300_600", syn.make_problem(11, 300, 600, seed=2))
+    record("shuffled_9_200_700", syn.make_problem(9, 200, 700, seed=3, window=9, shuffle=True))
+    record("nonortho_6_60_200", nonortho_problem())
+    record("edge_5_13", edge_problem(), jac=False, solve=False, tight=False)   # FD across Z == 0 is meaningless
+    record("ladybug_49_7776_31843", syn.make_shape("ladybug", seed=0), jac=False, tight_nfev=60)
+
+
+if __name__ == "__main__":
+    main()

@@ -191,8 +191,8 @@ struct sfmba_handle {
     // device memory
     DBuf<int> pt_ptr, pm_cam, pm_pt, pm_orig, cm_pt, chunk_cam, chunk_beg, cam_chunk_ptr;
     DBuf<double2> pm_uv, cm_uv;
-    DBuf<double2> cams[2];
-    DBuf<double4> X[2];
+    DBuf<double2> cams[2], cams0;
+    DBuf<double4> X[2], X0;
     DBuf<double> pm_sx, pm_sy, pm_siz, pm_ru, pm_rv, cm_sx, cm_sy, cm_siz;
     DBuf<double> V, gp, Vinv, chunk_part, UG, T, Minv, rhs;
     DBuf<double4> s, s0;
@@ -545,6 +545,10 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d) {
     h->cams[1].alloc(cams.size());
     h->X[0].upload(X, h->stream);
     h->X[1].alloc(X.size());
+    h->cams0.alloc(cams.size());
+    h->X0.alloc(X.size());
+    HIP_TRY(hipMemcpyAsync(h->cams0.p, h->cams[0].p, cams.size() * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+    if (!X.empty()) HIP_TRY(hipMemcpyAsync(h->X0.p, h->X[0].p, X.size() * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->linearized = false;
     refresh_dev(h);
@@ -736,6 +740,17 @@ int sfmba_set_params(sfmba_handle* h, const double* camera_params, const double*
         need_problem(h, "sfmba_set_params");
         if (!camera_params || !points_3d) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_params: null array");
         do_set_params(h, camera_params, points_3d);
+    });
+}
+
+int sfmba_reset_params(sfmba_handle* h) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_reset_params");
+        h->cur = 0;
+        HIP_TRY(hipMemcpyAsync(h->cams[0].p, h->cams0.p, h->cams0.n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+        if (h->X0.n) HIP_TRY(hipMemcpyAsync(h->X[0].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+        h->linearized = false;
+        refresh_dev(h);
     });
 }
 

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmba.s
 # every symbol include/sfmba.h declares
 EXPORTS = (
     "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error",
-    "sfmba_set_problem", "sfmba_set_params", "sfmba_residuals", "sfmba_jacobian_blocks",
+    "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
     "sfmba_solve", "sfmba_get_params", "sfmba_linearize", "sfmba_get_blocks",
     "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_solve_step",
     "sfmba_comm_unique_id", "sfmba_comm_init",
@@ -90,6 +90,7 @@ def load_library(path=None):
     lib.sfmba_last_error.restype = C.c_char_p
     lib.sfmba_set_problem.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp, dp, ip, ip, dp, dp]
     lib.sfmba_set_params.argtypes = [vp, dp, dp]
+    lib.sfmba_reset_params.argtypes = [vp]
     lib.sfmba_residuals.argtypes = [vp, dp]
     lib.sfmba_jacobian_blocks.argtypes = [vp, dp, dp]
     lib.sfmba_solve.argtypes = [vp, C.POINTER(Stats)]
@@ -196,6 +197,9 @@ class Engine:
         if cp.shape != (self.n_cameras, 12) or pts.shape != (self.n_points, 3):
             raise ValueError("parameter shapes do not match the loaded problem")
         self._check(self._lib.sfmba_set_params(self._h, _dp(cp), _dp(pts)))
+
+    def reset_params(self):
+        self._check(self._lib.sfmba_reset_params(self._h))
 
     def get_params(self):
         cp = np.empty((self.n_cameras, 12))

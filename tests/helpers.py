@@ -1,0 +1,109 @@
+"""Shared test helpers: golden fixtures, error measures and the chain rule that maps the
+engine's 2x6 / 2x3 Jacobian blocks to the reference's 12+3 columns per observation
+(/root/reference/bundle_adjustment.py:53-74)."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names(need=None):
+    out = []
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+        if need is None:
+            out.append(os.path.basename(path)[:-4])
+        else:
+            with np.load(path) as z:
+                if need in z.files:
+                    out.append(os.path.basename(path)[:-4])
+    return out
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    g["n_cameras"] = g["camera_params"].shape[0]
+    g["n_points"] = g["points_3d"].shape[0]
+    g["n_obs"] = g["camera_indices"].size
+    return g
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def elementwise_rel(a, b, floor=1.0):
+    """max |a-b| / max(|b|, floor): relative per element, absolute below `floor`."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def _skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def blocks_to_reference_jacobian(jc, jp, camera_params, camera_indices, point_indices, n_points):
+    """CSR (2*n_obs) x (12*n_cameras + 3*n_points) Jacobian in the reference's parameterisation
+    from blocks in the engine's: columns (dw, dt) of the left perturbation Y' = exp([dw]x)Y + dt.
+
+    For the raw rotation entry R_ij: with R = Q P (polar), dQ = Q [w]x where
+    (tr(P) I - P) w = axial(Q' E_ij - E_ij' Q); the left rotation is Q w and the translation
+    stays fixed, i.e. dt = t x (Q w)."""
+    cp = np.asarray(camera_params, dtype=np.float64)
+    n_cam = cp.shape[0]
+    ci = np.asarray(camera_indices)
+    pi = np.asarray(point_indices)
+    n_obs = ci.size
+    # per camera: 6 x 12 matrix mapping d(raw 12) -> (dw, dt)
+    M = np.zeros((n_cam, 6, 12))
+    for c in range(n_cam):
+        R = cp[c, :9].reshape(3, 3)
+        U, _, Vt = np.linalg.svd(R)
+        Q = U @ Vt
+        P = Q.T @ R
+        A = np.trace(P) * np.eye(3) - P
+        t = cp[c, 9:12]
+        for i in range(3):
+            for j in range(3):
+                E = np.zeros((3, 3)); E[i, j] = 1.0
+                S = Q.T @ E - E.T @ Q
+                a = np.array([S[2, 1], S[0, 2], S[1, 0]])
+                w = np.linalg.solve(A, a)
+                om = Q @ w
+                M[c, :3, 3 * i + j] = om
+                M[c, 3:, 3 * i + j] = np.cross(t, om)
+        M[c, 3:, 9:12] = np.eye(3)
+    J12 = np.einsum("nki,nij->nkj", jc, M[ci])          # (n_obs, 2, 12)
+    vals = np.concatenate([J12, jp], axis=2)             # (n_obs, 2, 15)
+    cols_obs = np.concatenate([ci[:, None] * 12 + np.arange(12)[None, :],
+                               n_cam * 12 + pi[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+    cols = np.repeat(cols_obs, 2, axis=0).ravel()
+    indptr = np.arange(0, 15 * 2 * n_obs + 1, 15)
+    J = csr_matrix((vals.reshape(-1), cols, indptr), shape=(2 * n_obs, 12 * n_cam + 3 * n_points))
+    J.sum_duplicates()
+    J.sort_indices()
+    return J
+
+
+def golden_jacobian(g):
+    n = 12 * g["n_cameras"] + 3 * g["n_points"]
+    return csr_matrix((g["jac_data"], g["jac_indices"], g["jac_indptr"]), shape=(2 * g["n_obs"], n))
+
+
+def identity_snapped_cameras(camera_params):
+    """Cameras whose rotation cv2.Rodrigues snaps to the identity (sin < 1e-5, cos > 0): the
+    reference's finite differences see no change there, so their rotation columns are zero."""
+    from oracle import ba_oracle as o
+    R = np.asarray(camera_params, dtype=np.float64)[:, :9].reshape(-1, 3, 3)
+    U, _, Vt = np.linalg.svd(R)
+    Q = U @ Vt
+    r = np.stack([Q[:, 2, 1] - Q[:, 1, 2], Q[:, 0, 2] - Q[:, 2, 0], Q[:, 1, 0] - Q[:, 0, 1]], axis=1)
+    s = np.sqrt((r * r).sum(axis=1) * 0.25)
+    c = (np.trace(Q, axis1=1, axis2=2) - 1) * 0.5
+    return np.flatnonzero((s < 1e-5) & (c > 0))

@@ -1,0 +1,87 @@
+"""GPU: size-independent properties at the benchmark's full size (Venice shape: 1 778 cameras,
+993 923 points, 5 001 946 observations), where the oracle is too slow to run."""
+import numpy as np
+import pytest
+
+from structure_from_motion_amd import synthetic as syn
+from structure_from_motion_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def venice():
+    return syn.make_shape("venice", seed=0)
+
+
+def _engine(p, **kw):
+    eng = Engine(**kw)
+    eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
+                    p["points_2d"], p["K"])
+    return eng
+
+
+def test_cost_checksum_across_kernels(venice):
+    # 0.5*||fun||^2 from the per-observation residual kernel == cost from the per-point linearisation
+    with _engine(venice, max_iterations=1) as eng:
+        f = eng.residuals()
+        st = eng.solve()
+    assert abs(0.5 * float(f @ f) - st.initial_cost) <= 1e-11 * st.initial_cost
+
+
+def test_residuals_at_truth_are_the_observation_noise(venice):
+    with _engine(venice) as eng:
+        eng.set_params(venice["true_camera_params"], venice["true_points_3d"])
+        f = eng.residuals()
+    rms = float(np.sqrt(np.mean(f * f)))
+    assert abs(rms - 0.5) < 0.002          # N(0, 0.5 px) on 10 M samples
+
+
+def test_gauge_invariance(venice):
+    # a global rigid motion of cameras and points leaves every residual unchanged
+    rng = np.random.default_rng(3)
+    G = syn._rodrigues(rng.normal(0, 0.7, (1, 3)))[0]
+    s = rng.normal(0, 2.0, 3)
+    cp = venice["camera_params"]
+    R = cp[:, :9].reshape(-1, 3, 3)
+    R2 = R @ G.T
+    t2 = cp[:, 9:12] - R2 @ s
+    X2 = venice["points_3d"] @ G.T + s
+    with _engine(venice) as eng:
+        f = eng.residuals()
+        eng.set_params(np.hstack([R2.reshape(-1, 9), t2]), X2)
+        f2 = eng.residuals()
+    assert np.abs(f - f2).max() <= 1e-8 * max(1.0, np.abs(f).max())
+
+
+def test_observation_order_does_not_matter(venice):
+    perm = np.random.default_rng(4).permutation(venice["n_obs"])
+    q = dict(venice)
+    q["camera_indices"] = venice["camera_indices"][perm]
+    q["point_indices"] = venice["point_indices"][perm]
+    q["points_2d"] = venice["points_2d"][perm]
+    with _engine(venice) as a, _engine(q) as b:
+        fa = a.residuals().reshape(-1, 2)
+        fb = b.residuals().reshape(-1, 2)
+        ca = a.solve().final_cost
+        cb = b.solve().final_cost
+    assert np.array_equal(fa[perm], fb)
+    # within a point the summation order follows the caller's order, so only rounding differs
+    assert abs(ca - cb) <= 1e-10 * ca
+
+
+def test_full_solve_converges_and_is_reproducible(venice):
+    with _engine(venice) as eng:
+        st = eng.solve()
+        poses, pts = eng.get_params()
+        # re-run from the same start on the same handle
+        eng.set_params(venice["camera_params"], venice["points_3d"])
+        st2 = eng.solve()
+    assert st.status in (1, 2, 3, 4)
+    assert st.final_cost < 0.01 * st.initial_cost
+    # at the optimum the cost is about (n_res - n_par)/2 * sigma^2
+    n_res = 2 * venice["n_obs"]; n_par = 6 * venice["n_cameras"] + 3 * venice["n_points"]
+    expect = 0.5 * (n_res - n_par) * 0.25
+    assert abs(st.final_cost - expect) < 0.01 * expect
+    assert st2.final_cost == st.final_cost
+    assert pts.shape == (venice["n_points"], 3) and poses.shape == (venice["n_cameras"], 12)

@@ -1,0 +1,90 @@
+"""CPU: host-side logic of the drop-in module and the synthetic generator (no GPU calls)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import ba_oracle as o
+from structure_from_motion_amd import bundle_adjustment as ba
+from structure_from_motion_amd import synthetic as syn
+
+
+class FakeView:
+    def __init__(self, vid, R, t):
+        self.id, self.rotation, self.translation = vid, R, t.reshape(3, 1)
+
+
+class FakeWorldPoints:
+    def __init__(self, pts, corr):
+        self.world_points, self.correspondences = pts, corr
+
+
+def _reference_view2idx(views, corr):
+    """The literal loops of /root/reference/bundle_adjustment.py:98-119."""
+    view_idx, camera_params = {}, []
+    for view in views:
+        if view.id not in view_idx:
+            view_idx[view.id] = len(view_idx)
+        rot_vec = np.squeeze(view.rotation)
+        camera_params.append(np.concatenate((rot_vec, view.translation.reshape((1, 3))), axis=None).tolist())
+    points_2d, camera_indices, point_indices = [], [], []
+    for i, row in corr.iterrows():
+        points_2d.append(row['FeatureIndex'][0]); camera_indices.append(view_idx[row['ViewId'][0]])
+        points_2d.append(row['FeatureIndex'][1]); camera_indices.append(view_idx[row['ViewId'][1]])
+        point_indices.append(i); point_indices.append(i)
+    return (np.array(camera_params), np.array(camera_indices), np.array(point_indices),
+            np.array(points_2d), view_idx)
+
+
+def test_view2idx_matches_reference_loops(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    p = syn.make_problem(5, 80, 160, seed=4, window=5)
+    views = [FakeView(f"id{j}", p["camera_params"][j, :9].reshape(3, 3), p["camera_params"][j, 9:]) for j in range(5)]
+    ci = p["camera_indices"].reshape(-1, 2)
+    uv = p["points_2d"].reshape(-1, 2, 2)
+    corr = pd.DataFrame({"ViewId": [[f"id{a}", f"id{b}"] for a, b in ci],
+                         "FeatureIndex": [[uv[i, 0], uv[i, 1]] for i in range(len(ci))]})
+    b = ba.BundleAdjustment(FakeWorldPoints(p["points_3d"], corr), p["K"], np.zeros((1, 5)), views)
+    b.view2idx()
+    cp, cidx, pidx, p2d, vidx = _reference_view2idx(views, corr)
+    assert np.array_equal(b.camera_params, cp) and np.array_equal(b.camera_indices, cidx)
+    assert np.array_equal(b.point_indices, pidx) and np.array_equal(b.points_2d, p2d)
+    assert b.view_idx == vidx and b.n_cameras == 5 and b.n_points == 80
+    assert b.focal_len == (p["K"][0, 0] + p["K"][1, 1]) / 2
+    with np.load(tmp_path / "optimize_data.npz") as z:
+        assert np.array_equal(z["points_2d"], p2d)
+
+
+def test_sparsity_mirror_equals_oracle():
+    p = syn.make_problem(4, 30, 90, seed=6, window=4)
+    A = ba.bundle_adjustment_sparsity(p["n_cameras"], p["n_points"], p["camera_indices"], p["point_indices"])
+    B = o.bundle_adjustment_sparsity(p["n_cameras"], p["n_points"], p["camera_indices"], p["point_indices"])
+    assert A.shape == B.shape and (A.tocsr() != B.tocsr()).nnz == 0 and A.dtype == B.dtype
+
+
+@pytest.mark.parametrize("shape", ["fountain", "ladybug"])
+def test_synthetic_shapes(shape):
+    p = syn.make_shape(shape, seed=0)
+    nc, npts, no = syn.SHAPES[shape]
+    assert p["camera_params"].shape == (nc, 12) and p["points_3d"].shape == (npts, 3)
+    assert p["camera_indices"].shape == (no,) and p["points_2d"].shape == (no, 2)
+    assert np.all(np.diff(p["point_indices"]) >= 0)                       # point-sorted
+    counts = np.bincount(p["point_indices"], minlength=npts)
+    assert counts.min() >= 2
+    pairs = p["camera_indices"] * npts + p["point_indices"]
+    assert np.unique(pairs).size == no                                    # no duplicate (cam, pt)
+    if shape == "fountain":
+        assert np.all(counts == 2)
+    R = p["true_camera_params"][:, :9].reshape(-1, 3, 3)
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12
+    # deterministic in the seed
+    q = syn.make_shape(shape, seed=0)
+    assert np.array_equal(p["points_2d"], q["points_2d"])
+
+
+def test_npz_round_trip(tmp_path):
+    p = syn.make_problem(4, 20, 50, seed=1, window=4)
+    syn.save_npz(tmp_path / "optimize_data.npz", p)
+    q = syn.load_npz(tmp_path / "optimize_data.npz")
+    for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d"):
+        assert np.array_equal(p[k], q[k])
+    assert abs(o.cost(p) - o.cost(q)) == 0
