@@ -1,0 +1,53 @@
+"""Condenses rocprofv3 CSV output (kernel trace + PMC passes) into a per-kernel table."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("sfmba::", "").replace("void ", "").strip()
+
+
+def main(out):
+    rows = []
+    trace = find(os.path.join(out, "trace"), "*kernel_trace.csv")
+    dur = defaultdict(list)
+    if trace:
+        with open(trace) as f:
+            for r in csv.DictReader(f):
+                dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    pmc = {}
+    for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        path = find(os.path.join(out, tag), "*counter_collection.csv")
+        acc = defaultdict(list)
+        if path:
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    if r.get("Counter_Name") == ctr:
+                        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        pmc[ctr] = acc
+    total = sum(sum(v) for v in dur.values())
+    print("| kernel | launches | avg us | total ms | % | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | HBM MB/launch (2x fetch + write) |")
+    print("|---|---|---|---|---|---|---|---|")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        if not k.startswith("k_"):
+            continue
+        fe = pmc["FETCH_SIZE"].get(k, [])
+        wr = pmc["WRITE_SIZE"].get(k, [])
+        fe_avg = sum(fe) / len(fe) if fe else float("nan")
+        wr_avg = sum(wr) / len(wr) if wr else float("nan")
+        mb = (2 * fe_avg + wr_avg) * 1024 / 1e6
+        print(f"| {k} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {sum(v) / 1e6:.3f} | {100 * sum(v) / total:.1f} | "
+              f"{fe_avg:.1f} | {wr_avg:.1f} | {mb:.2f} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
