@@ -63,6 +63,7 @@ typedef struct sfmba_options {
     double initial_lambda;    /* initial damping; 0 = 1e-4 */
     double pcg_rtol;          /* PCG stops at sqrt(r'M^-1 r / r0'M^-1 r0) <= pcg_rtol; 0 = 0.1 */
     int32_t pcg_max_iter;     /* 0 = 1000 */
+    int32_t pcg_batch;        /* PCG iterations queued per host check; 0 = 4 (pipelined), 1 = check every iteration */
     int32_t linear_solver;    /* enum sfmba_linear_solver */
     int32_t dense_max_dim;    /* 0 = 1536 */
     int32_t verbose;          /* 2 prints one line per LM iteration (SciPy verbose=2 columns) */

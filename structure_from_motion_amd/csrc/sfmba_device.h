@@ -211,6 +211,15 @@ __device__ __forceinline__ void so3_exp(const double* w, double* E) {
     E[8] = 1.0 + b * (w[2] * w[2] - t2);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  This maps the
+// hardware block id to a logical one so that each XCD works on one contiguous range of the
+// grid: neighbouring logical blocks touch neighbouring cameras / points, whose gathered rows
+// then stay in that XCD's L2.  Bijective for every grid size; affects speed only.
+__device__ __forceinline__ int xcd_block(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // ---- reductions over a 64-lane wavefront / a workgroup ---------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -186,7 +186,7 @@ struct sfmba_handle {
     int64_t pt_lo = 0, pt_hi = 0;          // owned point range
     int n_pts = 0, n_obs = 0, n_chunks = 0, nb_cam = 0;
     int chunk = kChunk;
-    std::vector<int> h_pm_orig;            // caller's observation index of each local observation
+    std::vector<int> new2old;              // internal (renumbered) local point id -> caller's local point id
 
     // device memory
     DBuf<int> pt_ptr, pm_cam, pm_pt, pm_orig, cm_pt, chunk_cam, chunk_beg, cam_chunk_ptr;
@@ -198,6 +198,8 @@ struct sfmba_handle {
     DBuf<double4> s, s0;
     DBuf<double> px, pr, pz, pp, pq, qS;
     DBuf<PcgState> pcg;
+    PcgState* pcg_host = nullptr;          // pinned, [2]
+    hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     DBuf<double> dot_part, scal_part, scalars;
     DBuf<double> tmp_a, tmp_b;             // API staging (residuals, Jacobian blocks, vectors)
     int cur = 0;                           // index of the current parameter buffers
@@ -217,6 +219,8 @@ struct sfmba_handle {
 
     ~sfmba_handle() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
+        for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
+        if (pcg_host) (void)hipHostFree(pcg_host);
         if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -345,9 +349,12 @@ int phase_pcg(H* h, double lambda) {
         Scope t(h, F_PCGVEC);
         launch_pcg_init(h->dev, tol, max_iter, h->stream);
     }
-    int cur = 0, queued = 0, batch = 4;
-    PcgState st{};
-    for (;;) {
+    // Iterations are queued in batches; the state of batch k is copied to pinned host memory
+    // behind it and only read after batch k+1 has been queued, so the GPU never waits for the
+    // host.  Kernels queued after convergence return at once (PcgState.done).
+    int batch = h->opt.pcg_batch > 0 ? h->opt.pcg_batch : 4;
+    int cur = 0, queued = 0;
+    auto queue_batch = [&](int slot) {
         for (int i = 0; i < batch; ++i) {
             schur_product(h, h->pp.p, true);
             Scope t(h, F_PCGVEC);
@@ -357,10 +364,20 @@ int phase_pcg(H* h, double lambda) {
             cur ^= 1;
             ++queued;
         }
-        HIP_TRY(hipMemcpyAsync(&st, h->pcg.p + cur, sizeof st, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (st.done || queued >= max_iter + batch) break;
-        if (batch < 32) batch *= 2;
+        HIP_TRY(hipMemcpyAsync(&h->pcg_host[slot], h->pcg.p + cur, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->pcg_ev[slot], h->stream));
+    };
+    const bool pipelined = batch > 1;
+    int slot = 0;
+    queue_batch(slot);
+    PcgState st{};
+    for (;;) {
+        if (pipelined) queue_batch(slot ^ 1);
+        HIP_TRY(hipEventSynchronize(h->pcg_ev[slot]));
+        st = h->pcg_host[slot];
+        if (st.done || queued >= max_iter + 2 * batch) break;
+        if (!pipelined) queue_batch(slot);
+        else slot ^= 1;
     }
     return st.iter;
 }
@@ -537,7 +554,7 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d) {
     pack_cameras(h, camera_params, cams);
     std::vector<double4> X((size_t)h->n_pts);
     for (int p = 0; p < h->n_pts; ++p) {
-        const double* x = points_3d + 3 * (h->pt_lo + p);
+        const double* x = points_3d + 3 * (h->pt_lo + h->new2old[p]);
         X[p] = make_double4(x[0], x[1], x[2], 0.0);
     }
     h->cur = 0;
@@ -591,18 +608,40 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->n_obs = (int)(pre[h->pt_hi] - pre[h->pt_lo]);
     const int np = h->n_pts, no = h->n_obs;
 
-    // point-major order of the owned observations (stable counting sort by point)
-    std::vector<int> pt_ptr((size_t)np + 1);
-    for (int p = 0; p <= np; ++p) pt_ptr[p] = (int)(pre[h->pt_lo + p] - pre[h->pt_lo]);
+    // Renumber the owned points by their smallest observing camera (counting sort, stable in the
+    // caller's point id).  Points seen by the same cameras then sit next to each other in HBM:
+    // the per-camera gathers of point data and the per-point gathers of camera data stay in L2.
+    std::vector<int> min_cam((size_t)np, (int)n_cam);   // n_cam = "unobserved", sorted last
+    for (int64_t i = 0; i < n_obs; ++i) {
+        int64_t p = pt_idx[i];
+        if (p < h->pt_lo || p >= h->pt_hi) continue;
+        int& m = min_cam[p - h->pt_lo];
+        if ((int)cam_idx[i] < m) m = (int)cam_idx[i];
+    }
+    std::vector<int> key_ptr((size_t)n_cam + 2, 0);
+    for (int p = 0; p < np; ++p) key_ptr[min_cam[p] + 1]++;
+    for (int64_t c = 0; c <= n_cam; ++c) key_ptr[c + 1] += key_ptr[c];
+    std::vector<int> old2new((size_t)np);
+    h->new2old.assign((size_t)np, 0);
+    for (int p = 0; p < np; ++p) {
+        int q = key_ptr[min_cam[p]]++;
+        old2new[p] = q;
+        h->new2old[q] = p;
+    }
+    // point-major order of the owned observations (stable counting sort by renumbered point)
+    std::vector<int> pt_ptr((size_t)np + 1, 0);
+    for (int p = 0; p < np; ++p) pt_ptr[old2new[p] + 1] = (int)(pre[h->pt_lo + p + 1] - pre[h->pt_lo + p]);
+    for (int p = 0; p < np; ++p) pt_ptr[p + 1] += pt_ptr[p];
     std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
     std::vector<int> pm_cam(no), pm_pt(no), pm_orig(no);
     std::vector<double2> pm_uv(no);
     for (int64_t i = 0; i < n_obs; ++i) {
         int64_t p = pt_idx[i];
         if (p < h->pt_lo || p >= h->pt_hi) continue;
-        int j = fill[p - h->pt_lo]++;
+        int q = old2new[p - h->pt_lo];
+        int j = fill[q]++;
         pm_cam[j] = (int)cam_idx[i];
-        pm_pt[j] = (int)(p - h->pt_lo);
+        pm_pt[j] = q;
         pm_orig[j] = (int)i;
         pm_uv[j] = make_double2(points_2d[2 * i], points_2d[2 * i + 1]);
     }
@@ -636,7 +675,6 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->pm_orig.upload(pm_orig, st); h->pm_uv.upload(pm_uv, st);
     h->cm_pt.upload(cm_pt, st); h->cm_uv.upload(cm_uv, st);
     h->chunk_cam.upload(chunk_cam, st); h->chunk_beg.upload(chunk_beg, st); h->cam_chunk_ptr.upload(cam_chunk_ptr, st);
-    h->h_pm_orig.swap(pm_orig);
     for (DBuf<double>* b : {&h->pm_sx, &h->pm_sy, &h->pm_siz, &h->pm_ru, &h->pm_rv, &h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
     h->V.alloc((size_t)np * 6); h->gp.alloc((size_t)np * 4); h->Vinv.alloc((size_t)np * 6);
     h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
@@ -710,6 +748,12 @@ int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
     if (dev >= n) { delete h; return SFMBA_ERR_NO_DEVICE; }
     h->device = dev;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return SFMBA_ERR_HIP;
+    }
+    if (hipHostMalloc((void**)&h->pcg_host, 2 * sizeof(PcgState), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->pcg_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->pcg_ev[1], hipEventDisableTiming) != hipSuccess) {
         delete h;
         return SFMBA_ERR_HIP;
     }
@@ -806,7 +850,7 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
                 // every rank returns all points: sum of zero-padded full-length arrays
                 std::vector<double> full((size_t)h->n_pts_all * 3, 0.0);
                 for (int p = 0; p < h->n_pts; ++p) {
-                    double* o = full.data() + 3 * (h->pt_lo + p);
+                    double* o = full.data() + 3 * (h->pt_lo + h->new2old[p]);
                     o[0] = X[p].x; o[1] = X[p].y; o[2] = X[p].z;
                 }
                 DBuf<double> d;
@@ -817,7 +861,7 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
                 HIP_TRY(hipStreamSynchronize(h->stream));
             } else {
                 for (int p = 0; p < h->n_pts; ++p) {
-                    double* o = points_3d + 3 * (h->pt_lo + p);
+                    double* o = points_3d + 3 * (h->pt_lo + h->new2old[p]);
                     o[0] = X[p].x; o[1] = X[p].y; o[2] = X[p].z;
                 }
             }
@@ -856,7 +900,7 @@ int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, doubl
             if (h->n_pts) HIP_TRY(hipMemcpy(v.data(), h->V.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (int p = 0; p < h->n_pts; ++p) {
                 const double* a = v.data() + 6 * (size_t)p;
-                double* o = V + 9 * (h->pt_lo + p);
+                double* o = V + 9 * (h->pt_lo + h->new2old[p]);
                 o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[1]; o[4] = a[3]; o[5] = a[4]; o[6] = a[2]; o[7] = a[4]; o[8] = a[5];
             }
         }
@@ -864,7 +908,7 @@ int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, doubl
             std::vector<double> g((size_t)h->n_pts * 4);
             if (h->n_pts) HIP_TRY(hipMemcpy(g.data(), h->gp.p, g.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (int p = 0; p < h->n_pts; ++p)
-                for (int i = 0; i < 3; ++i) g_pt[3 * (h->pt_lo + p) + i] = g[4 * (size_t)p + i];
+                for (int i = 0; i < 3; ++i) g_pt[3 * (h->pt_lo + h->new2old[p]) + i] = g[4 * (size_t)p + i];
         }
     });
 }
@@ -899,9 +943,13 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
         dp.alloc((size_t)std::max(h->n_pts, 1) * 3);
         phase_trial(h, dp.p);
         if (step_cam) HIP_TRY(hipMemcpyAsync(step_cam, h->px.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        std::vector<double> hdp((size_t)h->n_pts * 3);
         if (step_pt && h->n_pts)
-            HIP_TRY(hipMemcpyAsync(step_pt + 3 * h->pt_lo, dp.p, (size_t)h->n_pts * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(hdp.data(), dp.p, hdp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (step_pt)
+            for (int p = 0; p < h->n_pts; ++p)
+                for (int i = 0; i < 3; ++i) step_pt[3 * (h->pt_lo + h->new2old[p]) + i] = hdp[3 * (size_t)p + i];
     });
 }
 

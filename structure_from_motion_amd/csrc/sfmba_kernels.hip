@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_jacobian_blocks(Dev d, double* __res
 // Linearisation, point-major half: seeds + residuals per observation, V_p and g_p per point.
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
     __shared__ double red[16];
-    int p = blockIdx.x * kBlock + threadIdx.x;
+    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     double cost = 0.0, gmax = 0.0;
     if (p < d.n_pts) {
         double4 X = d.X[p];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
 // partials of U_c (21 packed upper) and g_c (6).
 __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_reduce(Dev d, int nvals, doubl
 // ------------------------------------------------------------------------------------------
 // Damping, per point: Vinv = (V + lambda * clamp(diag V))^-1 and s0 = Vinv g_p.
 __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
-    int p = blockIdx.x * kBlock + threadIdx.x;
+    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (p >= d.n_pts) return;
     const double* Vi = d.V + 6 * (size_t)p;
     double V[6];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
 // W = Jc' Jp (6x3).
 __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_precond(Dev d, double lambda) {
 // Schur matvec, point-major half: s_p = Vinv_p * sum_o Jp' (Jc x_c).
 __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restrict__ x, int check_done) {
     if (check_done && d.pcg->done) return;
-    int p = blockIdx.x * kBlock + threadIdx.x;
+    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (p >= d.n_pts) return;
     double t[3] = {0, 0, 0};
     int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restr
 __global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, int check_done) {
     if (check_done && d.pcg->done) return;
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __r
 __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
                                                     double* __restrict__ dp_out) {
     __shared__ double red[16];
-    int p = blockIdx.x * kBlock + threadIdx.x;
+    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     double model = 0.0, step2 = 0.0, x2 = 0.0;
     if (p < d.n_pts) {
         double t[3] = {0, 0, 0};
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __re
 // Cost at the trial point (cams_trial, X_trial).
 __global__ __launch_bounds__(kBlock) void k_cost_pm(Dev d) {
     __shared__ double red[16];
-    int p = blockIdx.x * kBlock + threadIdx.x;
+    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     double cost = 0.0, bad = 0.0;
     if (p < d.n_pts) {
         double4 X = d.X_trial[p];

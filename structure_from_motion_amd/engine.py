@@ -39,7 +39,7 @@ class Options(C.Structure):
         ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
         ("max_nfev", C.c_int32), ("max_iterations", C.c_int32),
         ("initial_lambda", C.c_double), ("pcg_rtol", C.c_double),
-        ("pcg_max_iter", C.c_int32), ("linear_solver", C.c_int32),
+        ("pcg_max_iter", C.c_int32), ("pcg_batch", C.c_int32), ("linear_solver", C.c_int32),
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
     ]
