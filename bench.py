@@ -137,7 +137,7 @@ def main():
         n_chunks = int(np.sum((cam_counts + chunk - 1) // chunk))
         ab = algorithmic_bytes(n_obs, p["n_points"], p["n_cameras"], n_chunks)
         families = {}
-        for fam in ("linearize", "damp", "spmv_pm", "spmv_cm", "pcg_vec", "back", "cost", "dense"):
+        for fam in ("linearize", "damp", "schur", "bsr", "spmv_pm", "spmv_cm", "pcg_vec", "back", "cost", "dense"):
             n = getattr(ps, "n_" + fam)
             ms = getattr(ps, "ms_" + fam)
             families[fam] = {"launches": int(n), "total_ms": ms, "avg_us": 1e3 * ms / n if n else 0.0}

@@ -65,6 +65,8 @@ typedef struct sfmba_options {
     int32_t pcg_max_iter;     /* 0 = 1000 */
     int32_t pcg_batch;        /* PCG iterations queued per host check; 0 = 4 (pipelined), 1 = check every iteration */
     int32_t linear_solver;    /* enum sfmba_linear_solver */
+    int32_t schur_mode;       /* 0 = auto, 1 = implicit (matrix-free matvec over the observations),
+                                 2 = explicit block-sparse camera-camera matrix */
     int32_t dense_max_dim;    /* 0 = 1536 */
     int32_t verbose;          /* 2 prints one line per LM iteration (SciPy verbose=2 columns) */
     int32_t profile;          /* 1 brackets every kernel family with HIP events (fills sfmba_stats.ms_*) */
@@ -83,7 +85,7 @@ typedef struct sfmba_stats {
     int32_t njev;             /* linearisations */
     int32_t pcg_iterations;   /* total PCG iterations (0 for the dense solver) */
     int32_t linear_solver;    /* solver actually used */
-    int32_t reserved;
+    int32_t schur_mode;       /* 1 implicit, 2 explicit */
     double initial_cost;      /* 0.5*||f||^2, SciPy's convention */
     double final_cost;
     double optimality;        /* inf-norm of the gradient at the final iterate */
@@ -97,7 +99,11 @@ typedef struct sfmba_stats {
     double ms_pcg_vec;    int64_t n_pcg_vec;   /* camera-vector kernels of PCG */
     double ms_back;       int64_t n_back;
     double ms_cost;       int64_t n_cost;
-    double ms_dense;      int64_t n_dense;     /* dense Schur assembly + Cholesky + solves */
+    double ms_dense;      int64_t n_dense;     /* dense Cholesky factorisation + solves */
+    double ms_schur;      int64_t n_schur;     /* explicit Schur assembly (pair kernel + reductions) */
+    double ms_bsr;        int64_t n_bsr;       /* block-CSR matvec of the explicit reduced system */
+    int64_t schur_pairs;                       /* observation pairs per assembly (explicit mode) */
+    int64_t schur_blocks;                      /* 6x6 blocks of the reduced matrix (explicit mode) */
 } sfmba_stats;
 
 /* Fill *opts with the defaults listed above. */

@@ -167,7 +167,7 @@ struct DBuf {
     DBuf& operator=(const DBuf&) = delete;
 };
 
-enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_COUNT };
+enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_COUNT };
 
 }  // namespace
 
@@ -202,6 +202,19 @@ struct sfmba_handle {
     hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     DBuf<double> dot_part, scal_part, scalars;
     DBuf<double> tmp_a, tmp_b;             // API staging (residuals, Jacobian blocks, vectors)
+    // explicit block-sparse Schur complement
+    bool explicit_schur = false;
+    int n_ublk = 0, n_pchunks = 0, nnzb = 0, nb_bsr = 0;
+    int64_t n_pairs = 0;
+    DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, pchunk_blk, pchunk_beg;
+    DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
+    DBuf<double> pair_part, Bsum, Sfull;
+    // dense Cholesky solver
+    bool use_dense = false;
+    int dense_n = 0;
+    DBuf<double> denseA, denseLinv;
+    DBuf<int> dense_fail;
+    int dense_fallbacks = 0;
     int cur = 0;                           // index of the current parameter buffers
     Dev dev{};
 
@@ -245,6 +258,14 @@ void refresh_dev(H* h) {
     d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p;
     d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp = h->pp.p; d.pq = h->pq.p; d.qS = h->qS.p;
     d.pcg = h->pcg.p; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
+    d.dot_off = std::max(h->nb_cam, h->nb_bsr);
+    d.n_ublk = h->n_ublk; d.n_pchunks = h->n_pchunks; d.nnzb = h->nnzb;
+    d.ublk_r = h->ublk_r.p; d.ublk_c = h->ublk_c.p; d.ublk_chunk_ptr = h->ublk_chunk_ptr.p;
+    d.ublk_pos = h->ublk_pos.p; d.ublk_pos_t = h->ublk_pos_t.p;
+    d.pchunk_blk = h->pchunk_blk.p; d.pchunk_beg = h->pchunk_beg.p;
+    d.pair_a = h->pair_a.p; d.pair_b = h->pair_b.p; d.pair_p = h->pair_p.p;
+    d.pair_part = h->pair_part.p; d.Bsum = h->Bsum.p;
+    d.bsr_ptr = h->bsr_ptr.p; d.bsr_col = h->bsr_col.p; d.bsr_diag = h->bsr_diag.p; d.Sfull = h->Sfull.p;
 }
 
 // ---- timing spans -------------------------------------------------------------------------
@@ -312,14 +333,35 @@ void phase_linearize(H* h) {
     h->linearized = false;
 }
 
-// Damp with lambda: Vinv, V*^-1 g_p, block-Jacobi blocks, reduced right-hand side.
+// Damp with lambda: Vinv, V*^-1 g_p, block-Jacobi blocks, reduced right-hand side; in explicit
+// mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
-    Scope t(h, F_DAMP);
-    launch_damp_pm(h->dev, lambda, h->stream);
-    launch_sdiag_cm(h->dev, h->stream);
-    launch_chunk_reduce(h->dev, 27, h->T.p, h->stream);
-    allreduce(h, h->T.p, (size_t)h->n_cam * 27);
-    launch_precond(h->dev, lambda, h->stream);
+    if (h->explicit_schur) {
+        {
+            Scope t(h, F_DAMP);
+            launch_damp_pm(h->dev, lambda, h->stream);
+            launch_spmv_cm(h->dev, h->s0.p, false, h->stream);           // sum W Vinv g_p
+            launch_chunk_reduce(h->dev, 6, h->qS.p, h->stream);
+        }
+        allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
+        {
+            Scope t(h, F_SCHUR);
+            launch_schur_pairs(h->dev, h->stream);
+        }
+        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36);
+        {
+            Scope t(h, F_SCHUR);
+            launch_schur_finish(h->dev, lambda, h->qS.p, h->stream);
+            launch_finalize_gmax_cam(h->dev, h->stream);
+        }
+    } else {
+        Scope t(h, F_DAMP);
+        launch_damp_pm(h->dev, lambda, h->stream);
+        launch_sdiag_cm(h->dev, h->stream);
+        launch_chunk_reduce(h->dev, 27, h->T.p, h->stream);
+        allreduce(h, h->T.p, (size_t)h->n_cam * 27);
+        launch_precond(h->dev, lambda, h->stream);
+    }
     h->linearized = true;
     h->lin_lambda = lambda;
 }
@@ -332,7 +374,7 @@ void schur_product(H* h, const double* x, bool check_done) {
     }
     {
         Scope t(h, F_SPMV_CM);
-        launch_spmv_cm(h->dev, check_done, h->stream);
+        launch_spmv_cm(h->dev, h->s.p, check_done, h->stream);
     }
     {
         Scope t(h, F_PCGVEC);
@@ -356,10 +398,19 @@ int phase_pcg(H* h, double lambda) {
     int cur = 0, queued = 0;
     auto queue_batch = [&](int slot) {
         for (int i = 0; i < batch; ++i) {
-            schur_product(h, h->pp.p, true);
+            int n_pq;
+            if (h->explicit_schur) {
+                Scope t(h, F_BSR);
+                launch_bsr_spmv(h->dev, h->pp.p, h->pq.p, h->dot_part.p, true, cur, h->stream);
+                n_pq = h->nb_bsr;
+            } else {
+                schur_product(h, h->pp.p, true);
+                Scope t(h, F_PCGVEC);
+                launch_pcg_q(h->dev, lambda, cur, h->stream);
+                n_pq = h->nb_cam;
+            }
             Scope t(h, F_PCGVEC);
-            launch_pcg_q(h->dev, lambda, cur, h->stream);
-            launch_pcg_update(h->dev, cur, h->stream);
+            launch_pcg_update(h->dev, cur, n_pq, h->stream);
             launch_pcg_dir(h->dev, cur, h->stream);
             cur ^= 1;
             ++queued;
@@ -380,6 +431,30 @@ int phase_pcg(H* h, double lambda) {
         else slot ^= 1;
     }
     return st.iter;
+}
+
+// Dense path: scatter S into a dense array, factor it on the matrix cores, solve for the camera
+// step.  Returns false when a pivot was not positive (caller falls back to PCG).
+bool phase_dense(H* h) {
+    Scope t(h, F_DENSE);
+    const int n = h->dense_n, n_real = 6 * (int)h->n_cam;
+    h->denseA.zero(h->stream);
+    h->dense_fail.zero(h->stream);
+    launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
+    launch_dense_cholesky_solve(h->denseA.p, n, n_real, h->denseLinv.p, h->dense_fail.p, h->rhs.p, h->px.p, h->stream);
+    int failed = 0;
+    HIP_TRY(hipMemcpyAsync(&failed, h->dense_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return failed == 0;
+}
+
+// Camera step of the damped normal equations into px; returns the PCG iteration count (0 = dense).
+int phase_linear_solve(H* h, double lambda) {
+    if (h->use_dense) {
+        if (phase_dense(h)) return 0;
+        h->dense_fallbacks++;
+    }
+    return phase_pcg(h, lambda);
 }
 
 // Step evaluation: back-substitution, retraction into the trial buffers, trial cost.
@@ -430,7 +505,7 @@ void do_solve(H* h, sfmba_stats* out) {
     double lambda = o.initial_lambda > 0 ? o.initial_lambda : 1e-4;
     double nu = 2.0;
     sfmba_stats st{};
-    st.linear_solver = SFMBA_SOLVER_PCG;
+    st.linear_solver = h->use_dense ? SFMBA_SOLVER_DENSE : SFMBA_SOLVER_PCG;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
@@ -461,7 +536,7 @@ void do_solve(H* h, sfmba_stats* out) {
             if (g_norm < gtol) { status = SFMBA_STATUS_GTOL; break; }
             if (st.nfev >= max_nfev) { status = SFMBA_STATUS_MAX_NFEV; break; }
         }
-        st.pcg_iterations += phase_pcg(h, lambda);
+        st.pcg_iterations += phase_linear_solve(h, lambda);
         phase_trial(h, nullptr);
         read_scalars(h, sc);
         st.nfev++;
@@ -522,6 +597,11 @@ void do_solve(H* h, sfmba_stats* out) {
     st.ms_back = h->fam_ms[F_BACK]; st.n_back = h->fam_n[F_BACK];
     st.ms_cost = h->fam_ms[F_COST]; st.n_cost = h->fam_n[F_COST];
     st.ms_dense = h->fam_ms[F_DENSE]; st.n_dense = h->fam_n[F_DENSE];
+    st.ms_schur = h->fam_ms[F_SCHUR]; st.n_schur = h->fam_n[F_SCHUR];
+    st.ms_bsr = h->fam_ms[F_BSR]; st.n_bsr = h->fam_n[F_BSR];
+    st.schur_mode = h->explicit_schur ? 2 : 1;
+    st.schur_pairs = h->explicit_schur ? h->n_pairs : 0;
+    st.schur_blocks = h->explicit_schur ? h->nnzb : 0;
     if (o.verbose >= 1 && o.rank <= 0) {
         static const char* msg[] = {"The maximum number of function evaluations is exceeded.",
                                     "`gtol` termination condition is satisfied.",
@@ -569,6 +649,181 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->linearized = false;
     refresh_dev(h);
+}
+
+
+int bsr_blocks_host(int n_cam) { Dev d{}; d.n_cam = n_cam; return bsr_blocks(d); }
+
+// Open-addressing set of 64-bit keys (camera pairs), with a small direct-mapped filter in
+// front: consecutive points mostly repeat the pairs of their neighbours.
+struct KeySet {
+    std::vector<uint64_t> tab, filt;
+    size_t mask, count = 0;
+    static constexpr uint64_t kEmpty = ~0ull;
+    KeySet() : tab(1u << 16, kEmpty), filt(1u << 14, kEmpty), mask((1u << 16) - 1) {}
+    static uint64_t mix(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return k ^ (k >> 29); }
+    void grow() {
+        std::vector<uint64_t> old;
+        old.swap(tab);
+        tab.assign(old.size() * 4, kEmpty);
+        mask = tab.size() - 1;
+        count = 0;
+        for (uint64_t k : old) if (k != kEmpty) put(k);
+    }
+    void put(uint64_t k) {
+        size_t i = mix(k) & mask;
+        while (tab[i] != kEmpty) { if (tab[i] == k) return; i = (i + 1) & mask; }
+        tab[i] = k;
+        if (++count * 2 > tab.size()) grow();
+    }
+    void insert(uint64_t k) {
+        uint64_t& f = filt[mix(k) & (filt.size() - 1)];
+        if (f == k) return;
+        f = k;
+        put(k);
+    }
+};
+
+// Structure of the explicit reduced matrix: upper blocks = camera pairs sharing a point (of ANY
+// rank, so that all ranks agree on the layout) plus every diagonal; per upper block the list of
+// this partition's observation pairs; the full block-CSR pattern and where each upper block and
+// its transpose land in it.
+void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, const int64_t* pt_idx,
+                           const std::vector<int64_t>& pre, const std::vector<int>& pt_ptr,
+                           const std::vector<int>& pm_cam, const std::vector<int>& pm_pt) {
+    const int n_cam = (int)h->n_cam, np = h->n_pts, no = h->n_obs;
+    int mode = h->opt.schur_mode;
+    if (const char* e = getenv("SFMBA_SCHUR_MODE")) mode = atoi(e);
+    int lin = h->opt.linear_solver;
+    if (const char* e = getenv("SFMBA_LINEAR_SOLVER")) lin = atoi(e);
+    const int dense_max = h->opt.dense_max_dim > 0 ? h->opt.dense_max_dim : 1536;
+    const bool want_dense = lin == SFMBA_SOLVER_DENSE || (lin == SFMBA_SOLVER_AUTO && 6 * (int64_t)n_cam <= dense_max);
+    if (6 * (int64_t)n_cam > 16384 && lin == SFMBA_SOLVER_DENSE)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)(6 * (int64_t)n_cam));
+    h->use_dense = false;
+    if (want_dense) mode = 2;          // the dense matrix is filled from the explicit blocks
+    h->explicit_schur = false;
+    h->n_ublk = h->n_pchunks = h->nnzb = 0;
+    h->n_pairs = 0;
+    if (mode == 1) return;
+    // pairs of this partition
+    int64_t n_pairs = 0;
+    for (int p = 0; p < np; ++p) {
+        const int64_t k = pt_ptr[p + 1] - pt_ptr[p];
+        n_pairs += k * (k + 1) / 2;
+    }
+    for (int p = 0; p < np; ++p)              // same-camera duplicates inside a point add one entry each
+        for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a)
+            for (int b = a + 1; b < pt_ptr[p + 1]; ++b)
+                if (pm_cam[a] == pm_cam[b]) ++n_pairs;
+    if (mode == 0 && (n_pairs > 24 * (int64_t)std::max(no, 1) || n_pairs > 1500000000LL)) return;
+    if (n_pairs > 2000000000LL) fail(SFMBA_ERR_INVALID_ARGUMENT, "explicit Schur complement: too many observation pairs");
+
+    // distinct camera pairs over all points of all ranks
+    KeySet keys;
+    auto key_of = [](int r, int c) { return ((uint64_t)(uint32_t)r << 32) | (uint32_t)c; };
+    if (h->n_obs == h->n_obs_all) {
+        for (int p = 0; p < np; ++p)
+            for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a)
+                for (int b = a + 1; b < pt_ptr[p + 1]; ++b) {
+                    const int ca = pm_cam[a], cb = pm_cam[b];
+                    if (ca != cb) keys.insert(key_of(std::min(ca, cb), std::max(ca, cb)));
+                }
+    } else {
+        std::vector<int> cams_by_pt((size_t)n_obs_all);
+        std::vector<int64_t> fillp(pre.begin(), pre.end() - 1);
+        for (int64_t i = 0; i < n_obs_all; ++i) cams_by_pt[fillp[pt_idx[i]]++] = (int)cam_idx[i];
+        for (int64_t p = 0; p < h->n_pts_all; ++p)
+            for (int64_t a = pre[p]; a < pre[p + 1]; ++a)
+                for (int64_t b = a + 1; b < pre[p + 1]; ++b) {
+                    const int ca = cams_by_pt[a], cb = cams_by_pt[b];
+                    if (ca != cb) keys.insert(key_of(std::min(ca, cb), std::max(ca, cb)));
+                }
+    }
+    std::vector<uint64_t> ukeys;
+    ukeys.reserve(keys.count + n_cam);
+    for (uint64_t k : keys.tab) if (k != KeySet::kEmpty) ukeys.push_back(k);
+    for (int c = 0; c < n_cam; ++c) ukeys.push_back(key_of(c, c));
+    std::sort(ukeys.begin(), ukeys.end());
+    const int n_ublk = (int)ukeys.size();
+    if (mode == 0 && (int64_t)n_ublk * 2 * 288 > (8LL << 30)) return;
+    std::vector<int> ur(n_ublk), uc(n_ublk), urow_ptr((size_t)n_cam + 1, 0);
+    for (int u = 0; u < n_ublk; ++u) { ur[u] = (int)(ukeys[u] >> 32); uc[u] = (int)(ukeys[u] & 0xffffffffu); urow_ptr[ur[u] + 1]++; }
+    for (int c = 0; c < n_cam; ++c) urow_ptr[c + 1] += urow_ptr[c];
+    auto find_blk = [&](int r, int c) {
+        const int* b = uc.data() + urow_ptr[r];
+        const int* e = uc.data() + urow_ptr[r + 1];
+        return (int)(std::lower_bound(b, e, c) - uc.data());
+    };
+    // count, then fill, the pair list of each upper block (points in increasing order)
+    std::vector<int> bcount((size_t)n_ublk + 1, 0);
+    auto for_each_pair = [&](auto&& emit) {
+        for (int p = 0; p < np; ++p)
+            for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a) {
+                const int ca = pm_cam[a];
+                emit(find_blk(ca, ca), a, a, p);
+                for (int b = a + 1; b < pt_ptr[p + 1]; ++b) {
+                    const int cb = pm_cam[b];
+                    if (ca == cb) { const int u = find_blk(ca, ca); emit(u, a, b, p); emit(u, b, a, p); }
+                    else if (ca < cb) emit(find_blk(ca, cb), a, b, p);
+                    else emit(find_blk(cb, ca), b, a, p);
+                }
+            }
+    };
+    for_each_pair([&](int u, int, int, int) { bcount[u + 1]++; });
+    for (int u = 0; u < n_ublk; ++u) bcount[u + 1] += bcount[u];
+    std::vector<int> pa((size_t)n_pairs), pb((size_t)n_pairs), pp((size_t)n_pairs);
+    {
+        std::vector<int> bf(bcount.begin(), bcount.end() - 1);
+        for_each_pair([&](int u, int a, int b, int p) { const int k = bf[u]++; pa[k] = a; pb[k] = b; pp[k] = p; });
+    }
+    (void)pm_pt;
+    // pair chunks
+    int pchunk = 512;
+    if (const char* e = getenv("SFMBA_PAIR_CHUNK")) { int v = atoi(e); if (v >= 64) pchunk = v; }
+    std::vector<int> pchunk_blk, pchunk_beg, ublk_chunk_ptr((size_t)n_ublk + 1, 0);
+    for (int u = 0; u < n_ublk; ++u) {
+        ublk_chunk_ptr[u] = (int)pchunk_blk.size();
+        for (int b = bcount[u]; b < bcount[u + 1]; b += pchunk) { pchunk_blk.push_back(u); pchunk_beg.push_back(b); }
+    }
+    ublk_chunk_ptr[n_ublk] = (int)pchunk_blk.size();
+    pchunk_beg.push_back((int)n_pairs);
+    // full block-CSR pattern
+    std::vector<int> bsr_ptr((size_t)n_cam + 1, 0);
+    for (int u = 0; u < n_ublk; ++u) { bsr_ptr[ur[u] + 1]++; if (ur[u] != uc[u]) bsr_ptr[uc[u] + 1]++; }
+    for (int c = 0; c < n_cam; ++c) bsr_ptr[c + 1] += bsr_ptr[c];
+    const int nnzb = bsr_ptr[n_cam];
+    std::vector<int> bsr_col((size_t)nnzb), bsr_diag((size_t)n_cam), upos(n_ublk), upos_t(n_ublk);
+    {
+        std::vector<int> rf(bsr_ptr.begin(), bsr_ptr.end() - 1);
+        for (int u = 0; u < n_ublk; ++u) {
+            const int r = ur[u], c = uc[u];
+            upos[u] = rf[r]++;
+            bsr_col[upos[u]] = c;
+            if (r == c) { upos_t[u] = upos[u]; bsr_diag[r] = upos[u]; }
+            else { upos_t[u] = rf[c]++; bsr_col[upos_t[u]] = r; }
+        }
+    }
+    hipStream_t st = h->stream;
+    h->ublk_r.upload(ur, st); h->ublk_c.upload(uc, st); h->ublk_chunk_ptr.upload(ublk_chunk_ptr, st);
+    h->ublk_pos.upload(upos, st); h->ublk_pos_t.upload(upos_t, st);
+    h->pchunk_blk.upload(pchunk_blk, st); h->pchunk_beg.upload(pchunk_beg, st);
+    h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
+    h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);
+    h->pair_part.alloc((size_t)std::max<size_t>(pchunk_blk.size(), 1) * 36);
+    h->Bsum.alloc((size_t)n_ublk * 36);
+    h->Sfull.alloc((size_t)nnzb * 36);
+    h->Bsum.zero(st); h->Sfull.zero(st);
+    HIP_TRY(hipStreamSynchronize(st));
+    h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
+    h->explicit_schur = true;
+    if (want_dense) {
+        h->dense_n = dense_padded(6 * n_cam);
+        h->denseA.alloc((size_t)h->dense_n * h->dense_n);
+        h->denseLinv.alloc((size_t)h->dense_n * 32);
+        h->dense_fail.alloc(1);
+        h->use_dense = true;
+    }
 }
 
 void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const double* camera_params,
@@ -682,7 +937,9 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->UG.alloc((size_t)n_cam * 27); h->T.alloc((size_t)n_cam * 27);
     h->Minv.alloc((size_t)n_cam * 36); h->rhs.alloc((size_t)n_cam * 6);
     for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp, &h->pq, &h->qS}) b->alloc((size_t)n_cam * 6);
-    h->pcg.alloc(2); h->dot_part.alloc((size_t)2 * h->nb_cam);
+    h->nb_bsr = bsr_blocks_host((int)n_cam);
+    h->pcg.alloc(2); h->dot_part.alloc((size_t)2 * std::max(h->nb_cam, h->nb_bsr));
+    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm_pt);
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
     h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
     h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * 36));
@@ -919,8 +1176,12 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y) {
         if (!x || !y) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_schur_matvec: null array");
         const size_t n = (size_t)h->n_cam * 6;
         HIP_TRY(hipMemcpyAsync(h->pz.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        schur_product(h, h->pz.p, false);
-        launch_schur_apply(h->dev, h->pz.p, h->lin_lambda, h->pq.p, h->stream);
+        if (h->explicit_schur) {
+            launch_bsr_spmv(h->dev, h->pz.p, h->pq.p, nullptr, false, 0, h->stream);
+        } else {
+            schur_product(h, h->pz.p, false);
+            launch_schur_apply(h->dev, h->pz.p, h->lin_lambda, h->pq.p, h->stream);
+        }
         HIP_TRY(hipMemcpyAsync(y, h->pq.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     });
@@ -937,7 +1198,7 @@ int sfmba_get_reduced(sfmba_handle* h, double* rhs, double* precond_inv) {
 int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t* pcg_iters) {
     return guarded(h, [&] {
         need_linearized(h, "sfmba_solve_step");
-        int it = phase_pcg(h, h->lin_lambda);
+        int it = phase_linear_solve(h, h->lin_lambda);
         if (pcg_iters) *pcg_iters = it;
         DBuf<double> dp;
         dp.alloc((size_t)std::max(h->n_pts, 1) * 3);

@@ -79,7 +79,21 @@ struct Dev {
     // PCG vectors, [n_cam][6]
     double* px; double* pr; double* pz; double* pp; double* pq; double* qS;
     PcgState* pcg;      // [2], double-buffered by iteration parity
-    double* dot_part;   // [2][ceil(n_cam/kBlock)] block partials of p'q and r'z
+    double* dot_part;   // block partials of p'q at [0, dot_off), of r'z at [dot_off, ...)
+    int dot_off;        // offset of the r'z partials inside dot_part (p'q partials start at 0)
+    // explicit block-sparse Schur complement (sfmba_schur.hip)
+    int n_ublk;               // upper blocks (row camera <= column camera), diagonal always present
+    int n_pchunks;            // pair chunks
+    int nnzb;                 // blocks of the full block-CSR matrix
+    const int* ublk_r; const int* ublk_c;         // [n_ublk]
+    const int* ublk_chunk_ptr;                    // [n_ublk+1] pair-chunk range of each upper block
+    const int* ublk_pos; const int* ublk_pos_t;   // [n_ublk] slots of (r,c) and (c,r) in Sfull
+    const int* pchunk_blk; const int* pchunk_beg; // [n_pchunks], [n_pchunks+1]
+    const int* pair_a; const int* pair_b; const int* pair_p;   // [n_pairs] pm indices of the two observations, point
+    double* pair_part;        // [n_pchunks][36]
+    double* Bsum;             // [n_ublk][36] sum W_a Vinv W_b' per upper block (all ranks' sum)
+    const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;   // [n_cam+1], [nnzb], [n_cam]
+    double* Sfull;            // [nnzb][36] row-major 6x6 blocks
     // scalars
     double* scal_part;  // [SLOT_COUNT][kMaxScalBlocks]
     double* scalars;    // [SLOT_COUNT]
@@ -95,15 +109,27 @@ void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);
 void launch_sdiag_cm(const Dev& d, hipStream_t st);             // chunk partials (27 values)
 void launch_precond(const Dev& d, double lambda, hipStream_t st);
 void launch_spmv_pm(const Dev& d, const double* x, bool check_done, hipStream_t st);
-void launch_spmv_cm(const Dev& d, bool check_done, hipStream_t st);   // chunk partials (6 values)
+void launch_spmv_cm(const Dev& d, const double4* svec, bool check_done, hipStream_t st);   // chunk partials (6 values)
 void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st);
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);
-void launch_pcg_update(const Dev& d, int cur, hipStream_t st);
+void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
 void launch_cost_pm(const Dev& d, hipStream_t st);
+void launch_finalize_gmax_cam(const Dev& d, hipStream_t st);
 int scal_blocks_pt(const Dev& d);
+int blocks_cam(const Dev& d);
+// sfmba_schur.hip
+int bsr_blocks(const Dev& d);
+void launch_schur_pairs(const Dev& d, hipStream_t st);
+void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st);
+void launch_bsr_spmv(const Dev& d, const double* x, double* y, double* dots, bool check_done, int cur, hipStream_t st);
+void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
+// sfmba_dense.hip
+int dense_padded(int n_real);
+void launch_dense_cholesky_solve(double* A, int n, int n_real, double* Linv_all, int* fail,
+                                 const double* b, double* x, hipStream_t st);
 
 }  // namespace sfmba

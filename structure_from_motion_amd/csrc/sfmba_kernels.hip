@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restr
 }
 
 // Schur matvec, camera-major half: chunk partials of sum_o Jc' (Jp s_p)  (6 values).
-__global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, int check_done) {
+__global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __restrict__ svec, int check_done) {
     if (check_done && d.pcg->done) return;
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, int check_done) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int k = k0 + lane; k < k1; k += 64) {
         Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
-        double4 sp = d.s[d.cm_pt[k]];
+        double4 sp = svec[d.cm_pt[k]];
         double dd[3] = {sp.x, sp.y, sp.z};
         double w0, w1;
         jp_times(s, d.K, cam.q, dd, w0, w1);
@@ -380,13 +380,13 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d) {
         }
     }
     double s = block_sum(dot, red);
-    if (threadIdx.x == 0) d.dot_part[gridDim.x + blockIdx.x] = s;
+    if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
 }
 
 __global__ void k_pcg_state_init(Dev d, int nb, double tol, int max_iter) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double rz = 0.0;
-    for (int i = 0; i < nb; ++i) rz += d.dot_part[nb + i];
+    for (int i = 0; i < nb; ++i) rz += d.dot_part[d.dot_off + i];
     PcgState st;
     st.rz = rz; st.rz0 = rz; st.tol2 = tol * tol; st.iter = 0; st.max_iter = max_iter;
     st.done = !(rz > 0.0);   // zero (or NaN) right-hand side: nothing to iterate on
@@ -418,12 +418,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_q(Dev d, double lambda, int cur)
 }
 
 // alpha = rz / p'q ; x += alpha p ; r -= alpha q ; z = Minv r ; block partials of r'z.
-__global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur) {
+__global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_parts) {
     __shared__ double red[16];
     if (d.pcg[cur].done) return;
-    const int nb = gridDim.x;
     double pq = 0.0;
-    for (int i = 0; i < nb; ++i) pq += d.dot_part[i];
+    for (int i = 0; i < n_pq_parts; ++i) pq += d.dot_part[i];
     const double alpha = d.pcg[cur].rz / pq;
     int c = blockIdx.x * kBlock + threadIdx.x;
     double dot = 0.0;
@@ -441,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur) {
         for (int i = 0; i < 6; ++i) { d.pz[6 * (size_t)c + i] = z[i]; dot += r[i] * z[i]; }
     }
     double s = block_sum(dot, red);
-    if (threadIdx.x == 0) d.dot_part[nb + blockIdx.x] = s;
+    if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
 }
 
 // beta = rz_new / rz ; p = z + beta p ; block 0 writes the next state.
@@ -453,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_dir(Dev d, int cur) {
     }
     const int nb = gridDim.x;
     double rz_new = 0.0;
-    for (int i = 0; i < nb; ++i) rz_new += d.dot_part[nb + i];
+    for (int i = 0; i < nb; ++i) rz_new += d.dot_part[d.dot_off + i];
     const double beta = rz_new / st.rz;
     int c = blockIdx.x * kBlock + threadIdx.x;
     if (c < d.n_cam) {
@@ -612,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_scal_finalize(Dev d, int first_slot,
 
 // ------------------------------------------------------------------------------------------
 int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
-static int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
+int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
 static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kBlock / 64); }
 
 void launch_residuals(const Dev& d, double* out, hipStream_t st) {
@@ -647,13 +646,16 @@ void launch_precond(const Dev& d, double lambda, hipStream_t st) {
     hipLaunchKernelGGL(k_precond, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda);
     hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(kBlock), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
 }
+void launch_finalize_gmax_cam(const Dev& d, hipStream_t st) {
+    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(kBlock), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
+}
 void launch_spmv_pm(const Dev& d, const double* x, bool check_done, hipStream_t st) {
     if (d.n_pts == 0) return;
     hipLaunchKernelGGL(k_spmv_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d, x, (int)check_done);
 }
-void launch_spmv_cm(const Dev& d, bool check_done, hipStream_t st) {
+void launch_spmv_cm(const Dev& d, const double4* svec, bool check_done, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    hipLaunchKernelGGL(k_spmv_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d, (int)check_done);
+    hipLaunchKernelGGL(k_spmv_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d, svec, (int)check_done);
 }
 void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
     hipLaunchKernelGGL(k_pcg_init, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d);
@@ -662,8 +664,8 @@ void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st) {
     hipLaunchKernelGGL(k_pcg_q, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
 }
-void launch_pcg_update(const Dev& d, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
+void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st) {
+    hipLaunchKernelGGL(k_pcg_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
 }
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st) {
     hipLaunchKernelGGL(k_pcg_dir, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);

@@ -1,0 +1,206 @@
+// Explicit block-sparse Schur complement of libsfmba (gfx950, fp64).
+//
+// S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p' has a 6x6 block for every pair of
+// cameras that share a point.  The host lists, per upper block (r <= c), the pairs of
+// observations (a, b) of one point with camera(a) = r and camera(b) = c, sorted by block and cut
+// into chunks; one wavefront owns one chunk, both cameras are wave-uniform, every lane forms
+//     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (6x2 . 2x2 . 2x6)
+// for its pairs from the stored seeds, sums in registers, and the wavefront reduces the 36 sums
+// with cross-lane shuffles into one partial row per chunk.  A per-block pass adds the chunk rows
+// in fixed order (bitwise reproducible, no atomics), a finishing pass mirrors the upper blocks
+// into a full block-CSR matrix and adds the damped U blocks on the diagonal.  The reduced system
+// is then small (Venice shape: 41 k blocks, 12 MB, L2/MALL resident) and PCG runs on it with a
+// block-CSR matvec; no observation is touched inside the PCG loop.
+//
+// This is the camera-camera accumulation that replaces the LSMR products J v / J' u of the
+// reference's solver (scipy/optimize/_lsq/trf.py:479-480, scipy/sparse/linalg/_isolve/lsmr.py).
+#include "sfmba_internal.h"
+
+namespace sfmba {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
+    const int lane = threadIdx.x & 63;
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_pchunks) return;
+    const int blk = __builtin_amdgcn_readfirstlane(d.pchunk_blk[q]);
+    const int k0 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q]);
+    const int k1 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q + 1]);
+    const int r = __builtin_amdgcn_readfirstlane(d.ublk_r[blk]);
+    const int c = __builtin_amdgcn_readfirstlane(d.ublk_c[blk]);
+    const Cam camr = load_cam(d.cams, r);
+    const Cam camc = load_cam(d.cams, c);
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        const int ja = d.pair_a[k], jb = d.pair_b[k], p = d.pair_p[k];
+        Seed sa; sa.x = d.pm_sx[ja]; sa.y = d.pm_sy[ja]; sa.iz = d.pm_siz[ja];
+        Seed sb; sb.x = d.pm_sx[jb]; sb.y = d.pm_sy[jb]; sb.iz = d.pm_siz[jb];
+        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
+        const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        double aa[3], ab[3], ba[3], bb[3];
+        jac_pt(sa, d.K, camr.q, aa, ab);     // rows of Jp_a
+        jac_pt(sb, d.K, camc.q, ba, bb);     // rows of Jp_b
+        // t0 = Vinv * ba, t1 = Vinv * bb  (Vinv packed upper: 00 01 02 11 12 22)
+        const double t00 = v01.x * ba[0] + v01.y * ba[1] + v23.x * ba[2];
+        const double t01 = v01.y * ba[0] + v23.y * ba[1] + v45.x * ba[2];
+        const double t02 = v23.x * ba[0] + v45.x * ba[1] + v45.y * ba[2];
+        const double t10 = v01.x * bb[0] + v01.y * bb[1] + v23.x * bb[2];
+        const double t11 = v01.y * bb[0] + v23.y * bb[1] + v45.x * bb[2];
+        const double t12 = v23.x * bb[0] + v45.x * bb[1] + v45.y * bb[2];
+        // M = Jp_a Vinv Jp_b'  (2x2)
+        const double m00 = aa[0] * t00 + aa[1] * t01 + aa[2] * t02;
+        const double m01 = aa[0] * t10 + aa[1] * t11 + aa[2] * t12;
+        const double m10 = ab[0] * t00 + ab[1] * t01 + ab[2] * t02;
+        const double m11 = ab[0] * t10 + ab[1] * t11 + ab[2] * t12;
+        double jca[12], jcb[12];
+        jac_cam(sa, d.K, jca);
+        jac_cam(sb, d.K, jcb);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double l0 = jca[i] * m00 + jca[6 + i] * m10;
+            const double l1 = jca[i] * m01 + jca[6 + i] * m11;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] += l0 * jcb[j] + l1 * jcb[6 + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        double* o = d.pair_part + 36 * (size_t)q;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) o[i] = acc[i];
+    }
+}
+
+// Bsum[u][e] = sum over the chunks of upper block u, fixed order.
+__global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.n_ublk * 36) return;
+    const int u = i / 36, e = i - 36 * u;
+    double s = 0.0;
+    for (int q = d.ublk_chunk_ptr[u]; q < d.ublk_chunk_ptr[u + 1]; ++q) s += d.pair_part[36 * (size_t)q + e];
+    d.Bsum[i] = s;
+}
+
+// Full block-CSR S from the (all-ranks) upper sums: S_rc = -B, S_cr = -B', S_rr = U*_r - B.
+__global__ __launch_bounds__(kBlock) void k_schur_finish(Dev d, double lambda) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= d.n_ublk * 36) return;
+    const int u = t / 36, e = t - 36 * u, i = e / 6, j = e - 6 * i;
+    const int r = d.ublk_r[u], c = d.ublk_c[u];
+    double v = -d.Bsum[t];
+    if (r == c) {
+        const double* U = d.UG + 27 * (size_t)r;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        double uv = U[upidx(6, a, b)];
+        if (i == j) uv += lambda * fmin(fmax(uv, 1e-6), 1e32);
+        d.Sfull[36 * (size_t)d.ublk_pos[u] + e] = uv + v;
+    } else {
+        d.Sfull[36 * (size_t)d.ublk_pos[u] + e] = v;
+        d.Sfull[36 * (size_t)d.ublk_pos_t[u] + 6 * j + i] = v;
+    }
+}
+
+// Inverse of the diagonal blocks of S (block-Jacobi preconditioner), reduced right-hand side
+// rhs = -g_c + sum W Vinv g_p, and the gradient maximum.  One thread per camera.
+__global__ __launch_bounds__(kBlock) void k_precond_explicit(Dev d, double lambda, const double* __restrict__ bpart) {
+    __shared__ double red[16];
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    double gmax = 0.0;
+    if (c < d.n_cam) {
+        const double* S = d.Sfull + 36 * (size_t)d.bsr_diag[c];
+        double A[6][6], Ai[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (S[6 * i + j] + S[6 * j + i]);
+        double dg[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dg[i] = A[i][i];
+        const bool ok = spd6_inverse(A, Ai);
+        double* o = d.Minv + 36 * (size_t)c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) o[6 * i + j] = ok ? Ai[i][j] : ((i == j) ? 1.0 / fmax(fabs(dg[i]), 1e-300) : 0.0);
+        const double* g = d.UG + 27 * (size_t)c + 21;
+        double* rr = d.rhs + 6 * (size_t)c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            rr[i] = -g[i] + bpart[6 * (size_t)c + i];
+            gmax = fmax(gmax, fabs(g[i]));
+        }
+    }
+    const double m = block_max(gmax, red);
+    if (threadIdx.x == 0) d.scal_part[(size_t)SLOT_GMAX_CAM * kMaxScalBlocks + blockIdx.x] = m;
+}
+
+// y = S x on the block-CSR matrix, one thread per (camera, row of the block); 42 cameras per
+// workgroup.  With dots != nullptr also the block partial of x'y (PCG: q = S p, p'q).
+constexpr int kCamsPerBlock = 42;
+
+__global__ __launch_bounds__(kBlock) void k_bsr_spmv(Dev d, const double* __restrict__ x, double* __restrict__ y,
+                                                     double* __restrict__ dots, int check_done, int cur) {
+    __shared__ double red[16];
+    if (check_done && d.pcg[cur].done) return;
+    const int local = threadIdx.x / 6, k = threadIdx.x - 6 * local;
+    const int c = blockIdx.x * kCamsPerBlock + local;
+    double dot = 0.0;
+    if (local < kCamsPerBlock && c < d.n_cam) {
+        double acc = 0.0;
+        const int b0 = d.bsr_ptr[c], b1 = d.bsr_ptr[c + 1];
+        for (int b = b0; b < b1; ++b) {
+            const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
+            const double2* xv = reinterpret_cast<const double2*>(x + 6 * (size_t)d.bsr_col[b]);
+            const double2 s0 = s[0], s1 = s[1], s2 = s[2];
+            const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
+            acc += s0.x * x0.x + s0.y * x0.y + s1.x * x1.x + s1.y * x1.y + s2.x * x2.x + s2.y * x2.y;
+        }
+        y[6 * (size_t)c + k] = acc;
+        dot = acc * x[6 * (size_t)c + k];
+    }
+    if (dots) {
+        const double s = block_sum(dot, red);
+        if (threadIdx.x == 0) dots[blockIdx.x] = s;
+    }
+}
+
+// Dense lower-triangular copy of S (row-major n x n, n = 6 n_cam) for the Cholesky solver.
+__global__ __launch_bounds__(kBlock) void k_bsr_to_dense(Dev d, double* __restrict__ A, int n) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= d.nnzb * 36) return;
+    const int b = t / 36, e = t - 36 * b, i = e / 6, j = e - 6 * i;
+    // row camera of block b: binary search in bsr_ptr
+    int lo = 0, hi = d.n_cam;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (d.bsr_ptr[mid] <= b) lo = mid; else hi = mid;
+    }
+    const int row = 6 * lo + i, col = 6 * d.bsr_col[b] + j;
+    A[(size_t)row * n + col] = d.Sfull[t];
+}
+
+int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerBlock); }
+
+void launch_schur_pairs(const Dev& d, hipStream_t st) {
+    if (d.n_pchunks > 0)
+        hipLaunchKernelGGL(k_schur_pairs, dim3(cdiv(d.n_pchunks, kBlock / 64)), dim3(kBlock), 0, st, d);
+    if (d.n_ublk > 0)
+        hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d);
+}
+void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st) {
+    if (d.n_ublk > 0)
+        hipLaunchKernelGGL(k_schur_finish, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d, lambda);
+    hipLaunchKernelGGL(k_precond_explicit, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, bpart);
+}
+void launch_bsr_spmv(const Dev& d, const double* x, double* y, double* dots, bool check_done, int cur, hipStream_t st) {
+    hipLaunchKernelGGL(k_bsr_spmv, dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y, dots, (int)check_done, cur);
+}
+void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_bsr_to_dense, dim3(cdiv(d.nnzb * 36, kBlock)), dim3(kBlock), 0, st, d, A, n);
+}
+
+}  // namespace sfmba

@@ -23,6 +23,7 @@ EXPORTS = (
 )
 
 SOLVER_AUTO, SOLVER_PCG, SOLVER_DENSE = 0, 1, 2
+SCHUR_AUTO, SCHUR_IMPLICIT, SCHUR_EXPLICIT = 0, 1, 2
 
 TERMINATION_MESSAGES = {   # scipy/optimize/_lsq/least_squares.py:18-25
     -1: "Improper input parameters status returned from `leastsq`",
@@ -39,7 +40,7 @@ class Options(C.Structure):
         ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
         ("max_nfev", C.c_int32), ("max_iterations", C.c_int32),
         ("initial_lambda", C.c_double), ("pcg_rtol", C.c_double),
-        ("pcg_max_iter", C.c_int32), ("pcg_batch", C.c_int32), ("linear_solver", C.c_int32),
+        ("pcg_max_iter", C.c_int32), ("pcg_batch", C.c_int32), ("linear_solver", C.c_int32), ("schur_mode", C.c_int32),
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
     ]
@@ -49,7 +50,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("iterations", C.c_int32), ("accepted", C.c_int32),
         ("nfev", C.c_int32), ("njev", C.c_int32), ("pcg_iterations", C.c_int32),
-        ("linear_solver", C.c_int32), ("reserved", C.c_int32),
+        ("linear_solver", C.c_int32), ("schur_mode", C.c_int32),
         ("initial_cost", C.c_double), ("final_cost", C.c_double),
         ("optimality", C.c_double), ("solve_seconds", C.c_double),
         ("ms_linearize", C.c_double), ("n_linearize", C.c_int64),
@@ -60,10 +61,13 @@ class Stats(C.Structure):
         ("ms_back", C.c_double), ("n_back", C.c_int64),
         ("ms_cost", C.c_double), ("n_cost", C.c_int64),
         ("ms_dense", C.c_double), ("n_dense", C.c_int64),
+        ("ms_schur", C.c_double), ("n_schur", C.c_int64),
+        ("ms_bsr", C.c_double), ("n_bsr", C.c_int64),
+        ("schur_pairs", C.c_int64), ("schur_blocks", C.c_int64),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        return {name: getattr(self, name) for name, _ in self._fields_ }
 
 
 class EngineError(RuntimeError):

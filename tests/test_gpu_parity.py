@@ -16,6 +16,12 @@ from structure_from_motion_amd.engine import Engine, EngineError
 
 pytestmark = pytest.mark.gpu
 
+# (linear_solver, schur_mode): PCG on the implicit operator, PCG on the explicit block-sparse
+# matrix, dense MFMA Cholesky on the explicit matrix
+SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
+           "pcg-explicit": dict(linear_solver=1, schur_mode=2),
+           "dense": dict(linear_solver=2)}
+
 
 def make_engine(g, **opts):
     eng = Engine(**opts)
@@ -128,15 +134,16 @@ def _model_system(g, lam):
     return dict(m=m, U=U, gc=gc, V=V, gp=gp, rhs=rhs, Minv=np.linalg.inv(Sd), matvec=matvec, dc=dc, dp=dp)
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("name", ["tiny_4_50_150", "shuffled_9_200_700", "edge_5_13"])
-def test_schur_blocks_matvec_and_step_match_model(name):
+def test_schur_blocks_matvec_and_step_match_model(name, solver):
     g = load_golden(name)
     if name == "edge_5_13":          # keep the degenerate structure, drop the Z == 0 singularity
         g["camera_params"] = g["camera_params"].copy()
         g["camera_params"][0, 11] += 4.0
     lam = 1e-3
     ref = _model_system(g, lam)
-    with make_engine(g, pcg_rtol=1e-13, pcg_max_iter=500) as eng:
+    with make_engine(g, pcg_rtol=1e-13, pcg_max_iter=500, **SOLVERS[solver]) as eng:
         eng.linearize(lam)
         U, gc, V, gp = eng.get_blocks()
         assert rel_err(U, ref["U"]) <= 1e-12 and rel_err(gc, ref["gc"]) <= 1e-12
@@ -147,18 +154,21 @@ def test_schur_blocks_matvec_and_step_match_model(name):
         x = np.random.default_rng(1).normal(size=ref["dc"].shape)
         assert rel_err(eng.schur_matvec(x), ref["matvec"](x)) <= 1e-12
         dc, dp, iters = eng.solve_step()
-        assert iters >= 1
+        assert (iters == 0) if solver == "dense" else (iters >= 1)
         assert rel_err(dc, ref["dc"]) <= 1e-7 and rel_err(dp, ref["dp"]) <= 1e-7
 
 
 # ------------------------------------------------------------------ full solves
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("name", golden_names("ref_cost"))
-def test_solve_with_reference_tolerances_not_worse_than_scipy(name):
+def test_solve_with_reference_tolerances_not_worse_than_scipy(name, solver):
     g = load_golden(name)
-    with make_engine(g) as eng:          # defaults = the reference's ftol/xtol
+    with make_engine(g, **SOLVERS[solver]) as eng:          # defaults = the reference's ftol/xtol
         st = eng.solve()
         poses, pts = eng.get_params()
     assert st.status in (1, 2, 3, 4)
+    assert st.linear_solver == (2 if solver == "dense" else 1)
+    assert st.schur_mode == (1 if solver == "pcg-implicit" else 2)
     assert abs(st.initial_cost - float(g["ref_initial_cost"])) <= 1e-10 * float(g["ref_initial_cost"])
     assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)
     # the returned 12-number poses reproduce the reported cost under the oracle's fun()
@@ -167,10 +177,12 @@ def test_solve_with_reference_tolerances_not_worse_than_scipy(name):
     assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("name", golden_names("tight_cost"))
-def test_converged_cost_matches_scipy(name):
+def test_converged_cost_matches_scipy(name, solver):
     g = load_golden(name)
-    with make_engine(g, ftol=1e-15, xtol=1e-15, gtol=1e-12, max_iterations=80, pcg_rtol=1e-3) as eng:
+    with make_engine(g, ftol=1e-15, xtol=1e-15, gtol=1e-12, max_iterations=80, pcg_rtol=1e-3,
+                     **SOLVERS[solver]) as eng:
         st = eng.solve()
     assert abs(st.final_cost - float(g["tight_cost"])) <= 1e-6 * float(g["tight_cost"])
 
@@ -229,7 +241,7 @@ def test_empty_observation_list():
 def test_two_partitions_sum_to_the_whole():
     g = load_golden("shuffled_9_200_700")
     lam = 1e-3
-    with make_engine(g) as whole:
+    with make_engine(g, linear_solver=1, schur_mode=1) as whole:
         whole.linearize(lam)
         U, gc, V, gp = whole.get_blocks()
         f = whole.residuals()
@@ -238,7 +250,7 @@ def test_two_partitions_sum_to_the_whole():
         y = whole.schur_matvec(x)
     parts = []
     for r in range(2):
-        with make_engine(g, rank=r, nranks=2) as eng:
+        with make_engine(g, rank=r, nranks=2, linear_solver=1, schur_mode=1) as eng:
             eng.linearize(lam)
             parts.append(eng.get_blocks() + (eng.residuals(),))
     assert rel_err(parts[0][0] + parts[1][0], U) <= 1e-12
