@@ -257,4 +257,59 @@ __device__ __forceinline__ double block_max(double v, double* scratch) {
     return r;
 }
 
+// ---- camera-sized dense helpers --------------------------------------------------------------
+// y = (U + lambda clamp(diag U)) x with U packed upper (21); y = M x with M full row-major 6x6.
+__device__ __forceinline__ void ustar_times(const double* U, double lambda, const double* x, double* y) {
+    double A[6][6];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) { A[i][j] = U[n]; A[j][i] = U[n]; ++n; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) A[i][i] += lambda * fmin(fmax(A[i][i], 1e-6), 1e32);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v += A[i][j] * x[j];
+        y[i] = v;
+    }
+}
+
+__device__ __forceinline__ void mat6_times(const double* M, const double* x, double* y) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v += M[6 * i + j] * x[j];
+        y[i] = v;
+    }
+}
+
+// ---- segments inside a wavefront ----------------------------------------------------------
+// Lanes carry a key; a segment is a run of consecutive lanes with the same key (the
+// observations of one point).  Inclusive segmented sums by log-step shuffles; the loop stops as
+// soon as no lane has a same-segment partner at the current distance.
+template <int N>
+__device__ __forceinline__ void seg_scan(double (&v)[N], int key, int lane) {
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ku = __shfl_up(key, off, 64);
+        const bool take = lane >= off && ku == key;
+        if (!__any(take)) break;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double u = __shfl_up(v[i], off, 64);
+            if (take) v[i] += u;
+        }
+    }
+}
+// Lane index of the last lane of this lane's segment.
+__device__ __forceinline__ int seg_last(int key, int lane) {
+    const int kn = __shfl_down(key, 1, 64);
+    const bool is_last = lane == 63 || kn != key;
+    const unsigned long long m = __ballot(is_last);
+    return lane + __builtin_ctzll(m >> lane);
+}
+
 }  // namespace sfmba

@@ -193,10 +193,13 @@ struct sfmba_handle {
     DBuf<double2> pm_uv, cm_uv;
     DBuf<double2> cams[2], cams0;
     DBuf<double4> X[2], X0;
-    DBuf<double> pm_sx, pm_sy, pm_siz, pm_ru, pm_rv, cm_sx, cm_sy, cm_siz;
+    DBuf<double4> pm_seed;
+    DBuf<int> wtile_beg;
+    int n_wtiles = 0;
+    DBuf<double> pm_rv, cm_sx, cm_sy, cm_siz;
     DBuf<double> V, gp, Vinv, chunk_part, UG, T, Minv, rhs;
     DBuf<double4> s, s0;
-    DBuf<double> px, pr, pz, pp, pq, qS;
+    DBuf<double> px, pr, pz, pp[2], pq, qS;
     DBuf<PcgState> pcg;
     PcgState* pcg_host = nullptr;          // pinned, [2]
     hipEvent_t pcg_ev[2] = {nullptr, nullptr};
@@ -204,7 +207,7 @@ struct sfmba_handle {
     DBuf<double> tmp_a, tmp_b;             // API staging (residuals, Jacobian blocks, vectors)
     // explicit block-sparse Schur complement
     bool explicit_schur = false;
-    int n_ublk = 0, n_pchunks = 0, nnzb = 0, nb_bsr = 0;
+    int n_ublk = 0, n_pchunks = 0, nnzb = 0, nb_bsr = 0, dot_off = 0;
     int64_t n_pairs = 0;
     DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, pchunk_blk, pchunk_beg;
     DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
@@ -251,14 +254,14 @@ void refresh_dev(H* h) {
     d.chunk_cam = h->chunk_cam.p; d.chunk_beg = h->chunk_beg.p; d.cam_chunk_ptr = h->cam_chunk_ptr.p;
     d.cams = h->cams[h->cur].p; d.X = h->X[h->cur].p;
     d.cams_trial = h->cams[h->cur ^ 1].p; d.X_trial = h->X[h->cur ^ 1].p;
-    d.pm_sx = h->pm_sx.p; d.pm_sy = h->pm_sy.p; d.pm_siz = h->pm_siz.p;
-    d.pm_ru = h->pm_ru.p; d.pm_rv = h->pm_rv.p;
+    d.pm_seed = h->pm_seed.p; d.pm_rv = h->pm_rv.p;
+    d.n_wtiles = h->n_wtiles; d.wtile_beg = h->wtile_beg.p;
     d.cm_sx = h->cm_sx.p; d.cm_sy = h->cm_sy.p; d.cm_siz = h->cm_siz.p;
     d.V = h->V.p; d.gp = h->gp.p; d.Vinv = h->Vinv.p; d.s = h->s.p; d.s0 = h->s0.p;
     d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p;
-    d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp = h->pp.p; d.pq = h->pq.p; d.qS = h->qS.p;
+    d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp[0] = h->pp[0].p; d.pp[1] = h->pp[1].p; d.pq = h->pq.p; d.qS = h->qS.p;
     d.pcg = h->pcg.p; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
-    d.dot_off = std::max(h->nb_cam, h->nb_bsr);
+    d.dot_off = h->dot_off;
     d.n_ublk = h->n_ublk; d.n_pchunks = h->n_pchunks; d.nnzb = h->nnzb;
     d.ublk_r = h->ublk_r.p; d.ublk_c = h->ublk_c.p; d.ublk_chunk_ptr = h->ublk_chunk_ptr.p;
     d.ublk_pos = h->ublk_pos.p; d.ublk_pos_t = h->ublk_pos_t.p;
@@ -340,7 +343,7 @@ void phase_damp(H* h, double lambda) {
         {
             Scope t(h, F_DAMP);
             launch_damp_pm(h->dev, lambda, h->stream);
-            launch_spmv_cm(h->dev, h->s0.p, false, h->stream);           // sum W Vinv g_p
+            launch_spmv_cm(h->dev, h->s0.p, nullptr, h->stream);         // sum W Vinv g_p
             launch_chunk_reduce(h->dev, 6, h->qS.p, h->stream);
         }
         allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
@@ -367,14 +370,14 @@ void phase_damp(H* h, double lambda) {
 }
 
 // qS = sum over observations of W Vinv W' x (this partition's part, then all ranks').
-void schur_product(H* h, const double* x, bool check_done) {
+void schur_product(H* h, const double* x, const PcgState* state) {
     {
         Scope t(h, F_SPMV_PM);
-        launch_spmv_pm(h->dev, x, check_done, h->stream);
+        launch_spmv_pm(h->dev, x, state, h->stream);
     }
     {
         Scope t(h, F_SPMV_CM);
-        launch_spmv_cm(h->dev, h->s.p, check_done, h->stream);
+        launch_spmv_cm(h->dev, h->s.p, state, h->stream);
     }
     {
         Scope t(h, F_PCGVEC);
@@ -401,17 +404,20 @@ int phase_pcg(H* h, double lambda) {
             int n_pq;
             if (h->explicit_schur) {
                 Scope t(h, F_BSR);
-                launch_bsr_spmv(h->dev, h->pp.p, h->pq.p, h->dot_part.p, true, cur, h->stream);
-                n_pq = h->nb_bsr;
+                launch_pcg_spmv_bsr(h->dev, cur, h->stream);
+                n_pq = pcg_spmv_blocks(h->dev);
             } else {
-                schur_product(h, h->pp.p, true);
+                {
+                    Scope t(h, F_PCGVEC);
+                    launch_pcg_dir(h->dev, cur, h->stream);
+                }
+                schur_product(h, h->pp[cur ^ 1].p, h->pcg.p + (cur ^ 1));
                 Scope t(h, F_PCGVEC);
                 launch_pcg_q(h->dev, lambda, cur, h->stream);
                 n_pq = h->nb_cam;
             }
             Scope t(h, F_PCGVEC);
             launch_pcg_update(h->dev, cur, n_pq, h->stream);
-            launch_pcg_dir(h->dev, cur, h->stream);
             cur ^= 1;
             ++queued;
         }
@@ -641,7 +647,7 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d) {
     h->cams[0].upload(cams, h->stream);
     h->cams[1].alloc(cams.size());
     h->X[0].upload(X, h->stream);
-    h->X[1].alloc(X.size());
+    h->X[1].upload(X, h->stream);       // points without observations are never rewritten
     h->cams0.alloc(cams.size());
     h->X0.alloc(X.size());
     HIP_TRY(hipMemcpyAsync(h->cams0.p, h->cams[0].p, cams.size() * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
@@ -930,15 +936,38 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->pm_orig.upload(pm_orig, st); h->pm_uv.upload(pm_uv, st);
     h->cm_pt.upload(cm_pt, st); h->cm_uv.upload(cm_uv, st);
     h->chunk_cam.upload(chunk_cam, st); h->chunk_beg.upload(chunk_beg, st); h->cam_chunk_ptr.upload(cam_chunk_ptr, st);
-    for (DBuf<double>* b : {&h->pm_sx, &h->pm_sy, &h->pm_siz, &h->pm_ru, &h->pm_rv, &h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
+    for (DBuf<double>* b : {&h->pm_rv, &h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
+    h->pm_seed.alloc((size_t)no);
+    {   // wave tiles of the point-major order: whole points, <= 64 observations (or one long point)
+        std::vector<int> wt;
+        int beg = 0;
+        for (int p = 0; p < np; ++p) {
+            const int k = pt_ptr[p + 1] - pt_ptr[p];
+            if (k == 0) continue;
+            if (pt_ptr[p + 1] - beg > 64 && pt_ptr[p] > beg) { wt.push_back(beg); beg = pt_ptr[p]; }
+            if (k > 64) { wt.push_back(beg); beg = pt_ptr[p + 1]; }
+        }
+        if (beg < no) wt.push_back(beg);
+        h->n_wtiles = (int)wt.size();
+        wt.push_back(no);
+        h->wtile_beg.upload(wt, st);
+        if ((h->n_wtiles + 3) / 4 > kMaxScalBlocks || (no + kBlock - 1) / kBlock > kMaxScalBlocks)
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many observations for one GPU");
+    }
     h->V.alloc((size_t)np * 6); h->gp.alloc((size_t)np * 4); h->Vinv.alloc((size_t)np * 6);
+    h->V.zero(st); h->gp.zero(st);      // points without observations are never written
     h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
     h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * 27);
     h->UG.alloc((size_t)n_cam * 27); h->T.alloc((size_t)n_cam * 27);
     h->Minv.alloc((size_t)n_cam * 36); h->rhs.alloc((size_t)n_cam * 6);
-    for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp, &h->pq, &h->qS}) b->alloc((size_t)n_cam * 6);
+    for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp[0], &h->pp[1], &h->pq, &h->qS}) b->alloc((size_t)n_cam * 6);
     h->nb_bsr = bsr_blocks_host((int)n_cam);
-    h->pcg.alloc(2); h->dot_part.alloc((size_t)2 * std::max(h->nb_cam, h->nb_bsr));
+    {
+        Dev t{};
+        t.n_cam = (int)n_cam;
+        h->dot_off = std::max(h->nb_cam, pcg_spmv_blocks(t));       // p'q partials, then r'z partials
+        h->pcg.alloc(2); h->dot_part.alloc((size_t)h->dot_off + pcg_update_blocks(t));
+    }
     build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm_pt);
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
     h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
@@ -1049,7 +1078,10 @@ int sfmba_reset_params(sfmba_handle* h) {
         need_problem(h, "sfmba_reset_params");
         h->cur = 0;
         HIP_TRY(hipMemcpyAsync(h->cams[0].p, h->cams0.p, h->cams0.n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-        if (h->X0.n) HIP_TRY(hipMemcpyAsync(h->X[0].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+        if (h->X0.n) {
+            HIP_TRY(hipMemcpyAsync(h->X[0].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->X[1].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+        }
         h->linearized = false;
         refresh_dev(h);
     });
@@ -1177,9 +1209,9 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y) {
         const size_t n = (size_t)h->n_cam * 6;
         HIP_TRY(hipMemcpyAsync(h->pz.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (h->explicit_schur) {
-            launch_bsr_spmv(h->dev, h->pz.p, h->pq.p, nullptr, false, 0, h->stream);
+            launch_bsr_spmv(h->dev, h->pz.p, h->pq.p, h->stream);
         } else {
-            schur_product(h, h->pz.p, false);
+            schur_product(h, h->pz.p, nullptr);
             launch_schur_apply(h->dev, h->pz.p, h->lin_lambda, h->pq.p, h->stream);
         }
         HIP_TRY(hipMemcpyAsync(y, h->pq.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1202,6 +1234,7 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
         if (pcg_iters) *pcg_iters = it;
         DBuf<double> dp;
         dp.alloc((size_t)std::max(h->n_pts, 1) * 3);
+        dp.zero(h->stream);                 // points without observations do not move
         phase_trial(h, dp.p);
         if (step_cam) HIP_TRY(hipMemcpyAsync(step_cam, h->px.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         std::vector<double> hdp((size_t)h->n_pts * 3);

@@ -10,7 +10,7 @@ namespace sfmba {
 
 constexpr int kBlock = 256;        // threads per workgroup of every kernel (4 wavefronts)
 constexpr int kChunk = 512;        // observations per camera-major chunk (one wavefront each)
-constexpr int kMaxScalBlocks = 65536;
+constexpr int kMaxScalBlocks = 1 << 18;
 
 // Scalar reduction slots (block partials -> k_scal_finalize -> scalars[slot]).
 enum Slot {
@@ -32,7 +32,7 @@ struct PcgState {
     double rz;        // r'z of the current iterate
     double rz0;       // r'z at iteration 0
     double tol2;      // stop when rz <= tol2 * rz0
-    int iter;
+    int iter;         // matvecs completed
     int max_iter;
     int done;
     int pad;
@@ -47,6 +47,9 @@ struct Dev {
     int n_chunks;         // camera-major chunks
     Intr K;
     // static structure
+    int n_wtiles;             // wave tiles of the point-major order
+    const int* wtile_beg;     // [n_wtiles+1] observation range of each tile: whole points, at most
+                              // 64 observations unless the tile is a single point with more
     const int* pt_ptr;        // [n_pts+1] CSR offsets into pm arrays
     const int* pm_cam;        // [n_obs]
     const int* pm_pt;         // [n_obs] local point id
@@ -63,8 +66,8 @@ struct Dev {
     double2* cams_trial;
     double4* X_trial;
     // linearisation products
-    double* pm_sx; double* pm_sy; double* pm_siz;   // seeds, point-major
-    double* pm_ru; double* pm_rv;                   // residuals, point-major
+    double4* pm_seed;   // [n_obs] (x, y, iz, ru): Jacobian seeds and the u residual, point-major
+    double* pm_rv;      // [n_obs] v residual, point-major
     double* cm_sx; double* cm_sy; double* cm_siz;   // seeds, camera-major
     double* V;          // [n_pts][6] packed upper J_p'J_p
     double* gp;         // [n_pts][4]
@@ -77,7 +80,8 @@ struct Dev {
     double* Minv;       // [n_cam][36] inverse of the block-Jacobi blocks
     double* rhs;        // [n_cam][6]
     // PCG vectors, [n_cam][6]
-    double* px; double* pr; double* pz; double* pp; double* pq; double* qS;
+    double* px; double* pr; double* pz; double* pq; double* qS;
+    double* pp[2];      // search direction, double-buffered by iteration parity
     PcgState* pcg;      // [2], double-buffered by iteration parity
     double* dot_part;   // block partials of p'q at [0, dot_off), of r'z at [dot_off, ...)
     int dot_off;        // offset of the r'z partials inside dot_part (p'q partials start at 0)
@@ -108,12 +112,17 @@ void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);
 void launch_sdiag_cm(const Dev& d, hipStream_t st);             // chunk partials (27 values)
 void launch_precond(const Dev& d, double lambda, hipStream_t st);
-void launch_spmv_pm(const Dev& d, const double* x, bool check_done, hipStream_t st);
-void launch_spmv_cm(const Dev& d, const double4* svec, bool check_done, hipStream_t st);   // chunk partials (6 values)
+void launch_spmv_pm(const Dev& d, const double* x, const PcgState* state, hipStream_t st);
+void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hipStream_t st);   // chunk partials (6 values)
+// sfmba_pcg.hip: one PCG iteration is  [head + direction (+ block-CSR matvec)]  [implicit
+// matvec kernels]  [update]; `cur` is the iteration parity (state and direction are double-buffered)
+int pcg_update_blocks(const Dev& d);
+int pcg_spmv_blocks(const Dev& d);
 void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st);
-void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);
+void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st);            // explicit mode
+void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);                 // implicit mode: direction only
+void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);    // implicit mode: q = U* p - qS
 void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
-void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
@@ -125,7 +134,7 @@ int blocks_cam(const Dev& d);
 int bsr_blocks(const Dev& d);
 void launch_schur_pairs(const Dev& d, hipStream_t st);
 void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st);
-void launch_bsr_spmv(const Dev& d, const double* x, double* y, double* dots, bool check_done, int cur, hipStream_t st);
+void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_dense.hip
 int dense_padded(int n_real);

@@ -57,44 +57,72 @@ __global__ __launch_bounds__(kBlock) void k_jacobian_blocks(Dev d, double* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// A wave tile: a range of point-major observations made of whole points, at most 64 of them
+// unless it is one single point with more (then the wave strides over it).  Lane l works on
+// observation beg + l, so every stream is read and written fully coalesced, and per-point sums
+// are segmented reductions over the lanes of a point.
+struct Tile { int beg, end; bool valid, is_long; };
+__device__ __forceinline__ Tile wave_tile(const Dev& d) {
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    Tile t;
+    t.valid = q < d.n_wtiles;
+    t.beg = t.valid ? __builtin_amdgcn_readfirstlane(d.wtile_beg[q]) : 0;
+    t.end = t.valid ? __builtin_amdgcn_readfirstlane(d.wtile_beg[q + 1]) : 0;
+    t.is_long = t.end - t.beg > 64;
+    return t;
+}
+
 // Linearisation, point-major half: seeds + residuals per observation, V_p and g_p per point.
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
     __shared__ double red[16];
-    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const Tile t = wave_tile(d);
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double cost = 0.0, gmax = 0.0;
-    if (p < d.n_pts) {
-        double4 X = d.X[p];
-        double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-        int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
-        for (int j = j0; j < j1; ++j) {
-            Cam k = load_cam(d.cams, d.pm_cam[j]);
-            Seed s = project_seed(k, X.x, X.y, X.z);
-            double2 uv = d.pm_uv[j];
-            double ru, rv;
-            residual(s, d.K, uv.x, uv.y, ru, rv);
-            d.pm_sx[j] = s.x; d.pm_sy[j] = s.y; d.pm_siz[j] = s.iz;
-            d.pm_ru[j] = ru; d.pm_rv[j] = rv;
-            double a[3], b[3];
-            jac_pt(s, d.K, k.q, a, b);
-            V[0] += a[0] * a[0] + b[0] * b[0];
-            V[1] += a[0] * a[1] + b[0] * b[1];
-            V[2] += a[0] * a[2] + b[0] * b[2];
-            V[3] += a[1] * a[1] + b[1] * b[1];
-            V[4] += a[1] * a[2] + b[1] * b[2];
-            V[5] += a[2] * a[2] + b[2] * b[2];
+    int key = -1 - lane;
+    for (int j = t.beg + lane; j < t.end; j += 64) {
+        const int p = d.pm_pt[j];
+        key = p;
+        const double4 X = d.X[p];
+        const Cam k = load_cam(d.cams, d.pm_cam[j]);
+        const Seed s = project_seed(k, X.x, X.y, X.z);
+        const double2 uv = d.pm_uv[j];
+        double ru, rv;
+        residual(s, d.K, uv.x, uv.y, ru, rv);
+        d.pm_seed[j] = make_double4(s.x, s.y, s.iz, ru);
+        d.pm_rv[j] = rv;
+        double a[3], b[3];
+        jac_pt(s, d.K, k.q, a, b);
+        acc[0] += a[0] * a[0] + b[0] * b[0];
+        acc[1] += a[0] * a[1] + b[0] * b[1];
+        acc[2] += a[0] * a[2] + b[0] * b[2];
+        acc[3] += a[1] * a[1] + b[1] * b[1];
+        acc[4] += a[1] * a[2] + b[1] * b[2];
+        acc[5] += a[2] * a[2] + b[2] * b[2];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) g[i] += a[i] * ru + b[i] * rv;
-            cost += ru * ru + rv * rv;
-        }
-        double* Vo = d.V + 6 * (size_t)p;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Vo[i] = V[i];
-        double* go = d.gp + 4 * (size_t)p;
-        go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; go[3] = 0.0;
-        gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+        for (int i = 0; i < 3; ++i) acc[6 + i] += a[i] * ru + b[i] * rv;
+        cost += ru * ru + rv * rv;
     }
-    double c = block_sum(cost, red);
-    double m = block_max(gmax, red);
+    bool writer;
+    if (t.is_long) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = wave_sum(acc[i]);
+        writer = lane == 0;
+    } else {
+        seg_scan(acc, key, lane);
+        const int last = seg_last(key, lane);      // every lane takes part in the shuffles
+        writer = key >= 0 && last == lane;
+    }
+    if (writer) {
+        double* Vo = d.V + 6 * (size_t)key;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Vo[i] = acc[i];
+        double* go = d.gp + 4 * (size_t)key;
+        go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
+        gmax = fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8])));
+    }
+    const double c = block_sum(cost, red);
+    const double m = block_max(gmax, red);
     if (threadIdx.x == 0) { put_partial(d, SLOT_COST, c); put_partial(d, SLOT_GMAX_PT, m); }
 }
 
@@ -271,38 +299,52 @@ __global__ __launch_bounds__(kBlock) void k_precond(Dev d, double lambda) {
 
 // ------------------------------------------------------------------------------------------
 // Schur matvec, point-major half: s_p = Vinv_p * sum_o Jp' (Jc x_c).
-__global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restrict__ x, int check_done) {
-    if (check_done && d.pcg->done) return;
-    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (p >= d.n_pts) return;
-    double t[3] = {0, 0, 0};
-    int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
-    for (int j = j0; j < j1; ++j) {
+__global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restrict__ x, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
+    const int lane = threadIdx.x & 63;
+    const Tile t = wave_tile(d);
+    double e[3] = {0, 0, 0};
+    int key = -1 - lane;
+    for (int j = t.beg + lane; j < t.end; j += 64) {
+        key = d.pm_pt[j];
         const int c = d.pm_cam[j];
-        Seed s; s.x = d.pm_sx[j]; s.y = d.pm_sy[j]; s.iz = d.pm_siz[j];
+        const double4 sd = d.pm_seed[j];
+        Seed s; s.x = sd.x; s.y = sd.y; s.iz = sd.z;
         const double2* xc = reinterpret_cast<const double2*>(x + 6 * (size_t)c);
-        double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
-        double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+        const double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
+        const double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
         double w0, w1;
         jc_times(s, d.K, dd, w0, w1);
         const double2* cq = d.cams + 6 * (size_t)c;
-        double2 q01 = cq[0], q23 = cq[1], q45 = cq[2], q67 = cq[3], q8 = cq[4];
-        double Q[9] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y, q8.x};
-        jpT_times_acc(s, d.K, Q, w0, w1, t);
+        const double2 q01 = cq[0], q23 = cq[1], q45 = cq[2], q67 = cq[3], q8 = cq[4];
+        const double Q[9] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y, q8.x};
+        jpT_times_acc(s, d.K, Q, w0, w1, e);
     }
-    const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
-    double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
-    double4 s;
-    s.x = v01.x * t[0] + v01.y * t[1] + v23.x * t[2];
-    s.y = v01.y * t[0] + v23.y * t[1] + v45.x * t[2];
-    s.z = v23.x * t[0] + v45.x * t[1] + v45.y * t[2];
-    s.w = 0.0;
-    d.s[p] = s;
+    bool writer;
+    if (t.is_long) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = wave_sum(e[i]);
+        writer = lane == 0;
+    } else {
+        seg_scan(e, key, lane);
+        const int last = seg_last(key, lane);      // every lane takes part in the shuffles
+        writer = key >= 0 && last == lane;
+    }
+    if (writer) {
+        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
+        const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        double4 sp;
+        sp.x = v01.x * e[0] + v01.y * e[1] + v23.x * e[2];
+        sp.y = v01.y * e[0] + v23.y * e[1] + v45.x * e[2];
+        sp.z = v23.x * e[0] + v45.x * e[1] + v45.y * e[2];
+        sp.w = 0.0;
+        d.s[key] = sp;
+    }
 }
 
 // Schur matvec, camera-major half: chunk partials of sum_o Jc' (Jp s_p)  (6 values).
-__global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __restrict__ svec, int check_done) {
-    if (check_done && d.pcg->done) return;
+__global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __restrict__ svec, const PcgState* __restrict__ state) {
+    if (state && state->done) return;
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
@@ -329,147 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// PCG on the reduced camera system, vectors [n_cam][6], one thread per camera.
-// PcgState is double-buffered: a kernel reads pcg[cur] and only k_pcg_dir writes pcg[cur^1].
-
-__device__ __forceinline__ void ustar_times(const double* U, double lambda, const double* x, double* y) {
-    double A[6][6];
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) { A[i][j] = U[n]; A[j][i] = U[n]; ++n; }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) A[i][i] += lambda * fmin(fmax(A[i][i], 1e-6), 1e32);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) v += A[i][j] * x[j];
-        y[i] = v;
-    }
-}
-
-__device__ __forceinline__ void mat6_times(const double* M, const double* x, double* y) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) v += M[6 * i + j] * x[j];
-        y[i] = v;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d) {
-    __shared__ double red[16];
-    int c = blockIdx.x * kBlock + threadIdx.x;
-    double dot = 0.0;
-    if (c < d.n_cam) {
-        const double* b = d.rhs + 6 * (size_t)c;
-        double r[6], z[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) r[i] = b[i];
-        mat6_times(d.Minv + 36 * (size_t)c, r, z);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            d.px[6 * (size_t)c + i] = 0.0;
-            d.pr[6 * (size_t)c + i] = r[i];
-            d.pz[6 * (size_t)c + i] = z[i];
-            d.pp[6 * (size_t)c + i] = z[i];
-            dot += r[i] * z[i];
-        }
-    }
-    double s = block_sum(dot, red);
-    if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
-}
-
-__global__ void k_pcg_state_init(Dev d, int nb, double tol, int max_iter) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double rz = 0.0;
-    for (int i = 0; i < nb; ++i) rz += d.dot_part[d.dot_off + i];
-    PcgState st;
-    st.rz = rz; st.rz0 = rz; st.tol2 = tol * tol; st.iter = 0; st.max_iter = max_iter;
-    st.done = !(rz > 0.0);   // zero (or NaN) right-hand side: nothing to iterate on
-    st.pad = 0;
-    d.pcg[0] = st;
-    d.pcg[1] = st;
-}
-
-// q = U* p - qS ; block partials of p'q.
-__global__ __launch_bounds__(kBlock) void k_pcg_q(Dev d, double lambda, int cur) {
-    __shared__ double red[16];
-    if (d.pcg[cur].done) return;
-    int c = blockIdx.x * kBlock + threadIdx.x;
-    double dot = 0.0;
-    if (c < d.n_cam) {
-        double p[6], q[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) p[i] = d.pp[6 * (size_t)c + i];
-        ustar_times(d.UG + 27 * (size_t)c, lambda, p, q);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            q[i] -= d.qS[6 * (size_t)c + i];
-            d.pq[6 * (size_t)c + i] = q[i];
-            dot += p[i] * q[i];
-        }
-    }
-    double s = block_sum(dot, red);
-    if (threadIdx.x == 0) d.dot_part[blockIdx.x] = s;
-}
-
-// alpha = rz / p'q ; x += alpha p ; r -= alpha q ; z = Minv r ; block partials of r'z.
-__global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_parts) {
-    __shared__ double red[16];
-    if (d.pcg[cur].done) return;
-    double pq = 0.0;
-    for (int i = 0; i < n_pq_parts; ++i) pq += d.dot_part[i];
-    const double alpha = d.pcg[cur].rz / pq;
-    int c = blockIdx.x * kBlock + threadIdx.x;
-    double dot = 0.0;
-    if (c < d.n_cam) {
-        double r[6], z[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            size_t o = 6 * (size_t)c + i;
-            d.px[o] += alpha * d.pp[o];
-            r[i] = d.pr[o] - alpha * d.pq[o];
-            d.pr[o] = r[i];
-        }
-        mat6_times(d.Minv + 36 * (size_t)c, r, z);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { d.pz[6 * (size_t)c + i] = z[i]; dot += r[i] * z[i]; }
-    }
-    double s = block_sum(dot, red);
-    if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
-}
-
-// beta = rz_new / rz ; p = z + beta p ; block 0 writes the next state.
-__global__ __launch_bounds__(kBlock) void k_pcg_dir(Dev d, int cur) {
-    const PcgState st = d.pcg[cur];
-    if (st.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg[cur ^ 1] = st;
-        return;
-    }
-    const int nb = gridDim.x;
-    double rz_new = 0.0;
-    for (int i = 0; i < nb; ++i) rz_new += d.dot_part[d.dot_off + i];
-    const double beta = rz_new / st.rz;
-    int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c < d.n_cam) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            size_t o = 6 * (size_t)c + i;
-            d.pp[o] = d.pz[o] + beta * d.pp[o];
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        PcgState nx = st;
-        nx.rz = rz_new;
-        nx.iter = st.iter + 1;
-        nx.done = (!(rz_new > nx.tol2 * nx.rz0)) || (nx.iter >= nx.max_iter);
-        d.pcg[cur ^ 1] = nx;
-    }
-}
+// Small dense helpers for the camera-sized vectors (the PCG kernels live in sfmba_pcg.hip).
 
 // y = U* x - qS  (diagnostic: one application of the reduced operator).
 __global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __restrict__ x,
@@ -487,56 +389,81 @@ __global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __r
 // ------------------------------------------------------------------------------------------
 // Back-substitution per point: dp = -Vinv (g_p + sum Jp' Jc dc); X_trial = X + dp; the cost of
 // the linear model at the step; |dp|^2 and |X|^2.
+struct BackObs { Seed s; double ru, rv, w0, w1; Cam k; };
+__device__ __forceinline__ BackObs back_load(const Dev& d, const double* __restrict__ dc, int j) {
+    BackObs o;
+    const int c = d.pm_cam[j];
+    const double4 sd = d.pm_seed[j];
+    o.s.x = sd.x; o.s.y = sd.y; o.s.iz = sd.z; o.ru = sd.w; o.rv = d.pm_rv[j];
+    const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)c);
+    const double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
+    const double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+    jc_times(o.s, d.K, dd, o.w0, o.w1);
+    o.k = load_cam(d.cams, c);
+    return o;
+}
+
 __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
                                                     double* __restrict__ dp_out) {
     __shared__ double red[16];
-    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const Tile t = wave_tile(d);
     double model = 0.0, step2 = 0.0, x2 = 0.0;
-    if (p < d.n_pts) {
-        double t[3] = {0, 0, 0};
-        int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
-        for (int j = j0; j < j1; ++j) {
-            const int c = d.pm_cam[j];
-            Seed s; s.x = d.pm_sx[j]; s.y = d.pm_sy[j]; s.iz = d.pm_siz[j];
-            const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)c);
-            double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
-            double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
-            double w0, w1;
-            jc_times(s, d.K, dd, w0, w1);
-            Cam k = load_cam(d.cams, c);
-            jpT_times_acc(s, d.K, k.q, w0, w1, t);
-        }
-        const double* g = d.gp + 4 * (size_t)p;
-        t[0] += g[0]; t[1] += g[1]; t[2] += g[2];
-        const double* vi = d.Vinv + 6 * (size_t)p;
-        double dp[3];
-        dp[0] = -(vi[0] * t[0] + vi[1] * t[1] + vi[2] * t[2]);
-        dp[1] = -(vi[1] * t[0] + vi[3] * t[1] + vi[4] * t[2]);
-        dp[2] = -(vi[2] * t[0] + vi[4] * t[1] + vi[5] * t[2]);
-        double4 X = d.X[p];
-        double4 Xn = X;
-        Xn.x += dp[0]; Xn.y += dp[1]; Xn.z += dp[2];
-        d.X_trial[p] = Xn;
-        if (dp_out) { dp_out[3 * (size_t)p] = dp[0]; dp_out[3 * (size_t)p + 1] = dp[1]; dp_out[3 * (size_t)p + 2] = dp[2]; }
+    double e[3] = {0, 0, 0};
+    int key = -1 - lane;
+    BackObs o{};
+    for (int j = t.beg + lane; j < t.end; j += 64) {
+        key = d.pm_pt[j];
+        o = back_load(d, dc, j);
+        jpT_times_acc(o.s, d.K, o.k.q, o.w0, o.w1, e);
+    }
+    bool writer;
+    if (t.is_long) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = wave_sum(e[i]);
+        key = __shfl(key, 0, 64);
+        writer = lane == 0;
+    } else {
+        seg_scan(e, key, lane);
+        const int last = seg_last(key, lane);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = __shfl(e[i], last, 64);
+        writer = key >= 0 && last == lane;
+    }
+    double dp[3] = {0, 0, 0};
+    if (key >= 0) {
+        const double* g = d.gp + 4 * (size_t)key;
+        const double t0 = e[0] + g[0], t1 = e[1] + g[1], t2 = e[2] + g[2];
+        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
+        const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        dp[0] = -(v01.x * t0 + v01.y * t1 + v23.x * t2);
+        dp[1] = -(v01.y * t0 + v23.y * t1 + v45.x * t2);
+        dp[2] = -(v23.x * t0 + v45.x * t1 + v45.y * t2);
+    }
+    if (writer) {
+        const double4 X = d.X[key];
+        d.X_trial[key] = make_double4(X.x + dp[0], X.y + dp[1], X.z + dp[2], 0.0);
+        if (dp_out) { dp_out[3 * (size_t)key] = dp[0]; dp_out[3 * (size_t)key + 1] = dp[1]; dp_out[3 * (size_t)key + 2] = dp[2]; }
         step2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
         x2 = X.x * X.x + X.y * X.y + X.z * X.z;
-        for (int j = j0; j < j1; ++j) {
-            const int c = d.pm_cam[j];
-            Seed s; s.x = d.pm_sx[j]; s.y = d.pm_sy[j]; s.iz = d.pm_siz[j];
-            const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)c);
-            double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
-            double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
-            double w0, w1, u0, u1;
-            jc_times(s, d.K, dd, w0, w1);
-            Cam k = load_cam(d.cams, c);
-            jp_times(s, d.K, k.q, dp, u0, u1);
-            double l0 = d.pm_ru[j] + w0 + u0, l1 = d.pm_rv[j] + w1 + u1;
+    }
+    if (t.is_long) {
+        for (int j = t.beg + lane; j < t.end; j += 64) {
+            const BackObs b = back_load(d, dc, j);
+            double u0, u1;
+            jp_times(b.s, d.K, b.k.q, dp, u0, u1);
+            const double l0 = b.ru + b.w0 + u0, l1 = b.rv + b.w1 + u1;
             model += l0 * l0 + l1 * l1;
         }
+    } else if (key >= 0) {
+        double u0, u1;
+        jp_times(o.s, d.K, o.k.q, dp, u0, u1);
+        const double l0 = o.ru + o.w0 + u0, l1 = o.rv + o.w1 + u1;
+        model = l0 * l0 + l1 * l1;
     }
-    double a = block_sum(model, red);
-    double b = block_sum(step2, red);
-    double c2 = block_sum(x2, red);
+    const double a = block_sum(model, red);
+    const double b = block_sum(step2, red);
+    const double c2 = block_sum(x2, red);
     if (threadIdx.x == 0) {
         put_partial(d, SLOT_MODEL, a);
         put_partial(d, SLOT_STEP2_PT, b);
@@ -574,43 +501,42 @@ __global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __re
     if (threadIdx.x == 0) { put_partial(d, SLOT_STEP2_CAM, a); put_partial(d, SLOT_X2_CAM, b); }
 }
 
-// Cost at the trial point (cams_trial, X_trial).
+// Cost at the trial point (cams_trial, X_trial): one thread per observation.
 __global__ __launch_bounds__(kBlock) void k_cost_pm(Dev d) {
     __shared__ double red[16];
-    int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const int j = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     double cost = 0.0, bad = 0.0;
-    if (p < d.n_pts) {
-        double4 X = d.X_trial[p];
-        int j0 = d.pt_ptr[p], j1 = d.pt_ptr[p + 1];
-        for (int j = j0; j < j1; ++j) {
-            Cam k = load_cam(d.cams_trial, d.pm_cam[j]);
-            Seed s = project_seed(k, X.x, X.y, X.z);
-            double2 uv = d.pm_uv[j];
-            double ru, rv;
-            residual(s, d.K, uv.x, uv.y, ru, rv);
-            double e = ru * ru + rv * rv;
-            if (isfinite(e)) cost += e; else bad += 1.0;
-        }
+    if (j < d.n_obs) {
+        const double4 X = d.X_trial[d.pm_pt[j]];
+        const Cam k = load_cam(d.cams_trial, d.pm_cam[j]);
+        const Seed s = project_seed(k, X.x, X.y, X.z);
+        const double2 uv = d.pm_uv[j];
+        double ru, rv;
+        residual(s, d.K, uv.x, uv.y, ru, rv);
+        const double e = ru * ru + rv * rv;
+        if (isfinite(e)) cost = e; else bad = 1.0;
     }
-    double a = block_sum(cost, red);
-    double b = block_sum(bad, red);
+    const double a = block_sum(cost, red);
+    const double b = block_sum(bad, red);
     if (threadIdx.x == 0) { put_partial(d, SLOT_TRIAL, a); put_partial(d, SLOT_NONFINITE, b); }
 }
 
 // scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per slot.
-__global__ __launch_bounds__(kBlock) void k_scal_finalize(Dev d, int first_slot, int nblocks, unsigned max_mask) {
+__global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, int nblocks, unsigned max_mask) {
     __shared__ double red[16];
     const int slot = first_slot + blockIdx.x;
     const bool is_max = (max_mask >> blockIdx.x) & 1u;
     const double* part = d.scal_part + (size_t)slot * kMaxScalBlocks;
     double v = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += kBlock) v = is_max ? fmax(v, part[i]) : v + part[i];
+    for (int i = threadIdx.x; i < nblocks; i += 1024) v = is_max ? fmax(v, part[i]) : v + part[i];
     double r = is_max ? block_max(v, red) : block_sum(v, red);
     if (threadIdx.x == 0) d.scalars[slot] = r;
 }
 
 // ------------------------------------------------------------------------------------------
 int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
+static int blocks_wtile(const Dev& d) { return cdiv(d.n_wtiles, kBlock / 64); }
+static int blocks_obs(const Dev& d) { return cdiv(d.n_obs, kBlock); }
 int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
 static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kBlock / 64); }
 
@@ -623,9 +549,9 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     hipLaunchKernelGGL(k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, jc, jp);
 }
 void launch_lin_pm(const Dev& d, hipStream_t st) {
-    if (d.n_pts == 0) return;
-    hipLaunchKernelGGL(k_lin_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(kBlock), 0, st, d, (int)SLOT_COST, scal_blocks_pt(d), 2u);
+    const int nb = blocks_wtile(d);
+    if (nb > 0) hipLaunchKernelGGL(k_lin_pm, dim3(nb), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
 }
 void launch_lin_cm(const Dev& d, hipStream_t st) {
     if (d.n_chunks == 0) return;
@@ -644,48 +570,35 @@ void launch_sdiag_cm(const Dev& d, hipStream_t st) {
 }
 void launch_precond(const Dev& d, double lambda, hipStream_t st) {
     hipLaunchKernelGGL(k_precond, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(kBlock), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
 }
 void launch_finalize_gmax_cam(const Dev& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(kBlock), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
 }
-void launch_spmv_pm(const Dev& d, const double* x, bool check_done, hipStream_t st) {
-    if (d.n_pts == 0) return;
-    hipLaunchKernelGGL(k_spmv_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d, x, (int)check_done);
+void launch_spmv_pm(const Dev& d, const double* x, const PcgState* state, hipStream_t st) {
+    if (d.n_wtiles == 0) return;
+    hipLaunchKernelGGL(k_spmv_pm, dim3(blocks_wtile(d)), dim3(kBlock), 0, st, d, x, state);
 }
-void launch_spmv_cm(const Dev& d, const double4* svec, bool check_done, hipStream_t st) {
+void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    hipLaunchKernelGGL(k_spmv_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d, svec, (int)check_done);
-}
-void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_init, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d);
-    hipLaunchKernelGGL(k_pcg_state_init, dim3(1), dim3(64), 0, st, d, blocks_cam(d), tol, max_iter);
-}
-void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_q, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
-}
-void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
-}
-void launch_pcg_dir(const Dev& d, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_dir, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
+    hipLaunchKernelGGL(k_spmv_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d, svec, state);
 }
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st) {
     hipLaunchKernelGGL(k_schur_apply, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, x, lambda, y);
 }
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st) {
-    if (d.n_pts == 0) return;
-    hipLaunchKernelGGL(k_back_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d, dc, dp_out);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(3), dim3(kBlock), 0, st, d, (int)SLOT_MODEL, scal_blocks_pt(d), 0u);
+    const int nb = blocks_wtile(d);
+    if (nb > 0) hipLaunchKernelGGL(k_back_pm, dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(3), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u);
 }
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st) {
     hipLaunchKernelGGL(k_cam_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, dc);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(kBlock), 0, st, d, (int)SLOT_STEP2_CAM, blocks_cam(d), 0u);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_STEP2_CAM, blocks_cam(d), 0u);
 }
 void launch_cost_pm(const Dev& d, hipStream_t st) {
-    if (d.n_pts == 0) return;
-    hipLaunchKernelGGL(k_cost_pm, dim3(scal_blocks_pt(d)), dim3(kBlock), 0, st, d);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(kBlock), 0, st, d, (int)SLOT_TRIAL, scal_blocks_pt(d), 0u);
+    const int nb = blocks_obs(d);
+    if (nb > 0) hipLaunchKernelGGL(k_cost_pm, dim3(nb), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_TRIAL, nb, 0u);
 }
 
 }  // namespace sfmba

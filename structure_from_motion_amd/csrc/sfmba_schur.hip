@@ -36,8 +36,9 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         const int ja = d.pair_a[k], jb = d.pair_b[k], p = d.pair_p[k];
-        Seed sa; sa.x = d.pm_sx[ja]; sa.y = d.pm_sy[ja]; sa.iz = d.pm_siz[ja];
-        Seed sb; sb.x = d.pm_sx[jb]; sb.y = d.pm_sy[jb]; sb.iz = d.pm_siz[jb];
+        const double4 da = d.pm_seed[ja], db = d.pm_seed[jb];
+        Seed sa; sa.x = da.x; sa.y = da.y; sa.iz = da.z;
+        Seed sb; sb.x = db.x; sb.y = db.y; sb.iz = db.z;
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
         const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
         double aa[3], ab[3], ba[3], bb[3];
@@ -139,33 +140,23 @@ __global__ __launch_bounds__(kBlock) void k_precond_explicit(Dev d, double lambd
 }
 
 // y = S x on the block-CSR matrix, one thread per (camera, row of the block); 42 cameras per
-// workgroup.  With dots != nullptr also the block partial of x'y (PCG: q = S p, p'q).
+// workgroup.  Diagnostic entry (sfmba_schur_matvec); PCG uses k_pcg_spmv_bsr.
 constexpr int kCamsPerBlock = 42;
 
-__global__ __launch_bounds__(kBlock) void k_bsr_spmv(Dev d, const double* __restrict__ x, double* __restrict__ y,
-                                                     double* __restrict__ dots, int check_done, int cur) {
-    __shared__ double red[16];
-    if (check_done && d.pcg[cur].done) return;
+__global__ __launch_bounds__(kBlock) void k_bsr_spmv(Dev d, const double* __restrict__ x, double* __restrict__ y) {
     const int local = threadIdx.x / 6, k = threadIdx.x - 6 * local;
     const int c = blockIdx.x * kCamsPerBlock + local;
-    double dot = 0.0;
-    if (local < kCamsPerBlock && c < d.n_cam) {
-        double acc = 0.0;
-        const int b0 = d.bsr_ptr[c], b1 = d.bsr_ptr[c + 1];
-        for (int b = b0; b < b1; ++b) {
-            const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
-            const double2* xv = reinterpret_cast<const double2*>(x + 6 * (size_t)d.bsr_col[b]);
-            const double2 s0 = s[0], s1 = s[1], s2 = s[2];
-            const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
-            acc += s0.x * x0.x + s0.y * x0.y + s1.x * x1.x + s1.y * x1.y + s2.x * x2.x + s2.y * x2.y;
-        }
-        y[6 * (size_t)c + k] = acc;
-        dot = acc * x[6 * (size_t)c + k];
+    if (local >= kCamsPerBlock || c >= d.n_cam) return;
+    double acc = 0.0;
+    const int b0 = d.bsr_ptr[c], b1 = d.bsr_ptr[c + 1];
+    for (int b = b0; b < b1; ++b) {
+        const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
+        const double2* xv = reinterpret_cast<const double2*>(x + 6 * (size_t)d.bsr_col[b]);
+        const double2 s0 = s[0], s1 = s[1], s2 = s[2];
+        const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
+        acc += s0.x * x0.x + s0.y * x0.y + s1.x * x1.x + s1.y * x1.y + s2.x * x2.x + s2.y * x2.y;
     }
-    if (dots) {
-        const double s = block_sum(dot, red);
-        if (threadIdx.x == 0) dots[blockIdx.x] = s;
-    }
+    y[6 * (size_t)c + k] = acc;
 }
 
 // Dense lower-triangular copy of S (row-major n x n, n = 6 n_cam) for the Cholesky solver.
@@ -196,8 +187,8 @@ void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipSt
         hipLaunchKernelGGL(k_schur_finish, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d, lambda);
     hipLaunchKernelGGL(k_precond_explicit, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, bpart);
 }
-void launch_bsr_spmv(const Dev& d, const double* x, double* y, double* dots, bool check_done, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_bsr_spmv, dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y, dots, (int)check_done, cur);
+void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st) {
+    hipLaunchKernelGGL(k_bsr_spmv, dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y);
 }
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_bsr_to_dense, dim3(cdiv(d.nnzb * 36, kBlock)), dim3(kBlock), 0, st, d, A, n);
