@@ -257,6 +257,43 @@ __device__ __forceinline__ double block_max(double v, double* scratch) {
     return r;
 }
 
+// Sum N per-lane values over the 64 lanes through a per-wave LDS tile instead of log-step
+// shuffles: in passes of H values every lane stores its H values as one row (row stride H+2
+// doubles, 16-byte aligned), then lane e < H adds column e over the 64 rows.  After the call
+// lane e (< H) holds the totals of values e, H+e, 2H+e, ... in out[0], out[1], ...
+// buf: 64*(H+2) doubles owned by this wave.  LDS operations of one wave complete in order, so a
+// wave-level barrier for the compiler plus a wait for outstanding LDS traffic is all the
+// synchronisation the hand-over between lanes needs.
+template <int N, int H>
+__device__ __forceinline__ void wave_sum_lds(const double (&acc)[N], double* buf, int lane,
+                                             double (&out)[(N + H - 1) / H]) {
+    static_assert(H % 2 == 0, "rows are written as 16-byte pairs");
+    constexpr int LD = H + 2;
+#pragma unroll
+    for (int p = 0; p < (N + H - 1) / H; ++p) {
+        double2* row = reinterpret_cast<double2*>(buf + lane * LD);
+#pragma unroll
+        for (int i = 0; i < H; i += 2) {
+            const int e0 = p * H + i, e1 = e0 + 1;
+            row[i / 2] = make_double2(e0 < N ? acc[e0] : 0.0, e1 < N ? acc[e1] : 0.0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (lane < H) {
+            const double* col = buf + lane;
+#pragma unroll
+            for (int r = 0; r < 64; r += 4) {
+                s0 += col[(r + 0) * LD]; s1 += col[(r + 1) * LD];
+                s2 += col[(r + 2) * LD]; s3 += col[(r + 3) * LD];
+            }
+        }
+        out[p] = (s0 + s1) + (s2 + s3);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- camera-sized dense helpers --------------------------------------------------------------
 // y = (U + lambda clamp(diag U)) x with U packed upper (21); y = M x with M full row-major 6x6.
 __device__ __forceinline__ void ustar_times(const double* U, double lambda, const double* x, double* y) {

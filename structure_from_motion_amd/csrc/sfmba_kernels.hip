@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
 // Linearisation, camera-major half: seeds per observation (camera-major copy) and the chunk
 // partials of U_c (21 packed upper) and g_c (6).
 __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
+    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc[21 + i] += jc[i] * ru + jc[6 + i] * rv;
     }
-#pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0) {
+    double tot[2];
+    wave_sum_lds<27, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);
+    if (lane < 14) {
         double* o = d.chunk_part + 27 * (size_t)q;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) o[i] = acc[i];
+        o[lane] = tot[0];
+        if (lane < 13) o[14 + lane] = tot[1];
     }
 }
 
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
 // Camera-major: chunk partials of T_c = sum W Vinv W' (21 packed upper) and sum W s0 (6),
 // W = Jc' Jp (6x3).
 __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
+    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
@@ -244,12 +246,12 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc[21 + i] += W[i][0] * s0.x + W[i][1] * s0.y + W[i][2] * s0.z;
     }
-#pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0) {
+    double tot[2];
+    wave_sum_lds<27, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);
+    if (lane < 14) {
         double* o = d.chunk_part + 27 * (size_t)q;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) o[i] = acc[i];
+        o[lane] = tot[0];
+        if (lane < 13) o[14 + lane] = tot[1];
     }
 }
 

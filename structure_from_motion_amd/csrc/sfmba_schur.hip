@@ -6,7 +6,7 @@
 // into chunks; one wavefront owns one chunk, both cameras are wave-uniform, every lane forms
 //     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (6x2 . 2x2 . 2x6)
 // for its pairs from the stored seeds, sums in registers, and the wavefront reduces the 36 sums
-// with cross-lane shuffles into one partial row per chunk.  A per-block pass adds the chunk rows
+// through an LDS tile into one partial row per chunk.  A per-block pass adds the chunk rows
 // in fixed order (bitwise reproducible, no atomics), a finishing pass mirrors the upper blocks
 // into a full block-CSR matrix and adds the damped U blocks on the diagonal.  The reduced system
 // is then small (Venice shape: 41 k blocks, 12 MB, L2/MALL resident) and PCG runs on it with a
@@ -21,6 +21,7 @@ namespace sfmba {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
+    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 20];
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_pchunks) return;
@@ -67,12 +68,12 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
             for (int j = 0; j < 6; ++j) acc[6 * i + j] += l0 * jcb[j] + l1 * jcb[6 + j];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0) {
+    double tot[2];
+    wave_sum_lds<36, 18>(acc, lds + (threadIdx.x >> 6) * (64 * 20), lane, tot);
+    if (lane < 18) {
         double* o = d.pair_part + 36 * (size_t)q;
-#pragma unroll
-        for (int i = 0; i < 36; ++i) o[i] = acc[i];
+        o[lane] = tot[0];
+        o[18 + lane] = tot[1];
     }
 }
 
