@@ -100,10 +100,12 @@ typedef struct sfmba_stats {
     double ms_back;       int64_t n_back;
     double ms_cost;       int64_t n_cost;
     double ms_dense;      int64_t n_dense;     /* dense Cholesky factorisation + solves */
-    double ms_schur;      int64_t n_schur;     /* explicit Schur assembly (pair kernel + reductions) */
+    double ms_schur;      int64_t n_schur;     /* explicit Schur assembly (pair kernel + reductions + finish) */
+    double ms_pairs;      int64_t n_pairs;     /* the pair kernel k_schur_pairs alone */
     double ms_bsr;        int64_t n_bsr;       /* block-CSR matvec of the explicit reduced system */
     int64_t schur_pairs;                       /* observation pairs per assembly (explicit mode) */
     int64_t schur_blocks;                      /* 6x6 blocks of the reduced matrix (explicit mode) */
+    int64_t schur_chunks;                      /* wavefront-sized pair chunks per assembly */
 } sfmba_stats;
 
 /* Fill *opts with the defaults listed above. */
@@ -176,6 +178,14 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
  * matvec partials and the cost partials of each iteration are all-reduced across ranks. */
 int sfmba_comm_unique_id(void* out128);
 int sfmba_comm_init(sfmba_handle* h, const void* unique_id128);
+
+/* Same decomposition inside ONE process: one handle per host thread (each on its own GPU, or
+ * several on one GPU), joined to an in-process group that all-reduces through device copies in
+ * rank order.  Every member must call sfmba_comm_init_local, and later sfmba_solve /
+ * sfmba_linearize / sfmba_get_params, concurrently from its own thread. */
+int sfmba_local_group_create(int32_t nranks, void** group);
+int sfmba_local_group_destroy(void* group);
+int sfmba_comm_init_local(sfmba_handle* h, void* group);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -167,7 +169,27 @@ struct DBuf {
     DBuf& operator=(const DBuf&) = delete;
 };
 
-enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_COUNT };
+// In-process group: the handles of several host threads of one process (one per GPU, or
+// several on one GPU) all-reduce through device copies instead of RCCL.
+struct LocalGroup {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    int next_rank_check = 0;
+    std::vector<double*> bufs;
+    std::vector<int> devices;
+    bool failed = false;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const long gen = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_PAIRS, F_COUNT };
 
 }  // namespace
 
@@ -223,6 +245,8 @@ struct sfmba_handle {
 
     // communication
     ncclComm_t comm = nullptr;
+    LocalGroup* group = nullptr;
+    bool has_comm() const { return comm != nullptr || group != nullptr; }
 
     // timing
     bool profile = false;
@@ -307,7 +331,29 @@ void collect_spans(H* h) {
 
 // ---- collectives --------------------------------------------------------------------------
 void allreduce(H* h, double* buf, size_t count) {
-    if (!h->comm || count == 0) return;
+    if (count == 0) return;
+    if (h->group) {
+        LocalGroup* g = h->group;
+        const int rk = h->opt.rank;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        g->bufs[rk] = buf;
+        g->barrier();
+        if (rk == 0) {                       // fixed rank order: bitwise reproducible
+            hipError_t e = hipSuccess;
+            for (int r = 1; r < g->n && e == hipSuccess; ++r) {
+                launch_vec_add(buf, g->bufs[r], count, h->stream);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            for (int r = 1; r < g->n && e == hipSuccess; ++r)
+                e = hipMemcpy(g->bufs[r], buf, count * sizeof(double), hipMemcpyDeviceToDevice);
+            g->failed = e != hipSuccess;
+        }
+        g->barrier();
+        if (g->failed) fail(SFMBA_ERR_COMM, "in-process all-reduce failed");
+        return;
+    }
+    if (!h->comm) return;
     ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, h->comm, h->stream);
     if (r != ncclSuccess) fail(SFMBA_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
 }
@@ -319,7 +365,7 @@ void read_scalars(H* h, double* out) {
 
 // Sum the partition-local scalar slots over ranks (the camera slots are replicated already).
 void reduce_scalars(H* h, int first, int count) {
-    if (!h->comm) return;
+    if (!h->has_comm()) return;
     allreduce(h, h->scalars.p + first, (size_t)count);
 }
 
@@ -349,7 +395,11 @@ void phase_damp(H* h, double lambda) {
         allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
         {
             Scope t(h, F_SCHUR);
-            launch_schur_pairs(h->dev, h->stream);
+            {
+                Scope t2(h, F_PAIRS);
+                launch_schur_pairs(h->dev, h->stream);
+            }
+            launch_block_reduce(h->dev, h->stream);
         }
         allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36);
         {
@@ -479,7 +529,7 @@ void phase_trial(H* h, double* dp_out) {
 
 double gather_gmax_pt(H* h, double local) {
     // max over ranks of a non-negative scalar through a sum all-reduce of one slot per rank
-    if (!h->comm) return local;
+    if (!h->has_comm()) return local;
     int nr = h->opt.nranks;
     std::vector<double> slots(nr, 0.0);
     slots[h->opt.rank] = local;
@@ -608,6 +658,8 @@ void do_solve(H* h, sfmba_stats* out) {
     st.schur_mode = h->explicit_schur ? 2 : 1;
     st.schur_pairs = h->explicit_schur ? h->n_pairs : 0;
     st.schur_blocks = h->explicit_schur ? h->nnzb : 0;
+    st.schur_chunks = h->explicit_schur ? h->n_pchunks : 0;
+    st.ms_pairs = h->fam_ms[F_PAIRS]; st.n_pairs = h->fam_n[F_PAIRS];
     if (o.verbose >= 1 && o.rank <= 0) {
         static const char* msg[] = {"The maximum number of function evaluations is exceeded.",
                                     "`gtol` termination condition is satisfied.",
@@ -1135,7 +1187,7 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
             std::vector<double4> X((size_t)h->n_pts);
             if (h->n_pts) HIP_TRY(hipMemcpyAsync(X.data(), h->X[h->cur].p, X.size() * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            if (h->comm) {
+            if (h->has_comm()) {
                 // every rank returns all points: sum of zero-padded full-length arrays
                 std::vector<double> full((size_t)h->n_pts_all * 3, 0.0);
                 for (int p = 0; p < h->n_pts; ++p) {
@@ -1269,6 +1321,48 @@ int sfmba_comm_init(sfmba_handle* h, const void* unique_id128) {
         memcpy(&id, unique_id128, sizeof id);
         ncclResult_t r = g_rccl.CommInitRank(&h->comm, h->opt.nranks, id, h->opt.rank);
         if (r != ncclSuccess) { h->comm = nullptr; fail(SFMBA_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    });
+}
+
+int sfmba_local_group_create(int32_t nranks, void** out) {
+    if (!out || nranks < 1 || nranks > 64) return SFMBA_ERR_INVALID_ARGUMENT;
+    LocalGroup* g = new (std::nothrow) LocalGroup();
+    if (!g) return SFMBA_ERR_INVALID_ARGUMENT;
+    g->n = nranks;
+    g->bufs.assign(nranks, nullptr);
+    g->devices.assign(nranks, -1);
+    *out = g;
+    return SFMBA_OK;
+}
+
+int sfmba_local_group_destroy(void* group) {
+    if (!group) return SFMBA_ERR_INVALID_ARGUMENT;
+    delete static_cast<LocalGroup*>(group);
+    return SFMBA_OK;
+}
+
+int sfmba_comm_init_local(sfmba_handle* h, void* group) {
+    return guarded(h, [&] {
+        LocalGroup* g = static_cast<LocalGroup*>(group);
+        if (!g) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_comm_init_local: null group");
+        if (h->opt.nranks != g->n || h->opt.rank < 0 || h->opt.rank >= g->n)
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_comm_init_local: rank %d of %d does not fit a group of %d", h->opt.rank, h->opt.nranks, g->n);
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            g->devices[h->opt.rank] = h->device;
+        }
+        g->barrier();
+        // every pair of devices in the group must be able to address each other's memory
+        for (int r = 0; r < g->n; ++r) {
+            if (g->devices[r] == h->device) continue;
+            int ok = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&ok, h->device, g->devices[r]));
+            if (!ok) fail(SFMBA_ERR_COMM, "device %d cannot access device %d", h->device, g->devices[r]);
+            hipError_t e = hipDeviceEnablePeerAccess(g->devices[r], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) throw HipError{e, "hipDeviceEnablePeerAccess"};
+            (void)hipGetLastError();
+        }
+        h->group = g;
     });
 }
 

@@ -129,10 +129,12 @@ void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
 void launch_cost_pm(const Dev& d, hipStream_t st);
 void launch_finalize_gmax_cam(const Dev& d, hipStream_t st);
 int scal_blocks_pt(const Dev& d);
+void launch_vec_add(double* a, const double* b, size_t n, hipStream_t st);
 int blocks_cam(const Dev& d);
 // sfmba_schur.hip
 int bsr_blocks(const Dev& d);
 void launch_schur_pairs(const Dev& d, hipStream_t st);
+void launch_block_reduce(const Dev& d, hipStream_t st);
 void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);

@@ -535,6 +535,15 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
     if (threadIdx.x == 0) d.scalars[slot] = r;
 }
 
+// a += b (in-process all-reduce of several handles)
+__global__ __launch_bounds__(kBlock) void k_vec_add(double* __restrict__ a, const double* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+void launch_vec_add(double* a, const double* b, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a, b, n);
+}
+
 // ------------------------------------------------------------------------------------------
 int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
 static int blocks_wtile(const Dev& d) { return cdiv(d.n_wtiles, kBlock / 64); }

@@ -180,6 +180,8 @@ int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerBlock); }
 void launch_schur_pairs(const Dev& d, hipStream_t st) {
     if (d.n_pchunks > 0)
         hipLaunchKernelGGL(k_schur_pairs, dim3(cdiv(d.n_pchunks, kBlock / 64)), dim3(kBlock), 0, st, d);
+}
+void launch_block_reduce(const Dev& d, hipStream_t st) {
     if (d.n_ublk > 0)
         hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d);
 }

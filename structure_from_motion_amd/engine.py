@@ -20,6 +20,7 @@ EXPORTS = (
     "sfmba_solve", "sfmba_get_params", "sfmba_linearize", "sfmba_get_blocks",
     "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_solve_step",
     "sfmba_comm_unique_id", "sfmba_comm_init",
+    "sfmba_local_group_create", "sfmba_local_group_destroy", "sfmba_comm_init_local",
 )
 
 SOLVER_AUTO, SOLVER_PCG, SOLVER_DENSE = 0, 1, 2
@@ -62,8 +63,9 @@ class Stats(C.Structure):
         ("ms_cost", C.c_double), ("n_cost", C.c_int64),
         ("ms_dense", C.c_double), ("n_dense", C.c_int64),
         ("ms_schur", C.c_double), ("n_schur", C.c_int64),
+        ("ms_pairs", C.c_double), ("n_pairs", C.c_int64),
         ("ms_bsr", C.c_double), ("n_bsr", C.c_int64),
-        ("schur_pairs", C.c_int64), ("schur_blocks", C.c_int64),
+        ("schur_pairs", C.c_int64), ("schur_blocks", C.c_int64), ("schur_chunks", C.c_int64),
     ]
 
     def as_dict(self):
@@ -106,6 +108,9 @@ def load_library(path=None):
     lib.sfmba_solve_step.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
     lib.sfmba_comm_unique_id.argtypes = [vp]
     lib.sfmba_comm_init.argtypes = [vp, vp]
+    lib.sfmba_local_group_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    lib.sfmba_local_group_destroy.argtypes = [vp]
+    lib.sfmba_comm_init_local.argtypes = [vp, vp]
     for name in EXPORTS:
         if name not in ("sfmba_default_options", "sfmba_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -265,6 +270,24 @@ class Engine:
             raise EngineError(rc, "could not obtain an RCCL unique id")
         return buf.raw
 
+    def comm_init_local(self, group):
+        """Join an in-process group made by `local_group_create` (call from this rank's thread)."""
+        self._check(self._lib.sfmba_comm_init_local(self._h, group))
+
     def comm_init(self, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self._lib.sfmba_comm_init(self._h, buf))
+
+
+def local_group_create(nranks):
+    """In-process communicator for `nranks` engines driven by `nranks` host threads."""
+    lib = load_library()
+    g = C.c_void_p()
+    rc = lib.sfmba_local_group_create(int(nranks), C.byref(g))
+    if rc != 0:
+        raise EngineError(rc, "sfmba_local_group_create failed")
+    return g
+
+
+def local_group_destroy(group):
+    load_library().sfmba_local_group_destroy(group)
