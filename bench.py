@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-scale", type=float, default=0.12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--linear-solver", type=int, default=0, help="0 auto, 1 PCG, 2 dense Cholesky")
+    ap.add_argument("--schur-mode", type=int, default=0, help="0 auto, 1 implicit, 2 explicit")
     args = ap.parse_args()
 
     import torch
@@ -95,7 +97,8 @@ def main():
         torch.cuda.set_device(local_rank)
 
     p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
-    eng = Engine(device=local_rank, rank=rank, nranks=world)
+    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode)
+    eng = Engine(device=local_rank, rank=rank, nranks=world, **solver_opts)
     t0 = time.time()
     eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
                     p["points_2d"], p["K"])
@@ -135,7 +138,7 @@ def main():
     # that did work, so it errs on the slow side.
     roof, families = None, None
     if world == 1:
-        prof_eng = Engine(device=local_rank, profile=1)
+        prof_eng = Engine(device=local_rank, profile=1, **solver_opts)
         prof_eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
                              p["points_2d"], p["K"])
         prof_eng.solve()
@@ -190,7 +193,9 @@ def main():
                                     f"{p['n_cameras']} cameras / {p['n_points']} points / {n_obs} observations; "
                                     "one step = one full LM solve (Schur complement + block-Jacobi PCG), "
                                     "ftol=1e-4 xtol=1e-12 gtol=1e-8"),
-                       "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU",
+                       "linear_solver": {1: "pcg", 2: "dense-cholesky"}[last.linear_solver],
+                       "schur_mode": {1: "implicit", 2: "explicit"}[last.schur_mode]},
             "lm_iters_per_sec": iters / elapsed,
             "lm_iterations_per_solve": iters / args.steps,
             "pcg_iterations_per_solve": sum(s.pcg_iterations for s in stats) / args.steps,

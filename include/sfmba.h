@@ -45,7 +45,8 @@ enum sfmba_status {
 };
 
 enum sfmba_linear_solver {
-    SFMBA_SOLVER_AUTO = 0, /* dense Cholesky when 6*n_cameras <= dense_max_dim, else PCG */
+    SFMBA_SOLVER_AUTO = 0, /* PCG; a step on which PCG runs out of iterations is re-solved by the dense
+                              Cholesky when 6*n_cameras <= dense_max_dim (sfmba_stats.n_dense counts them) */
     SFMBA_SOLVER_PCG = 1,  /* block-Jacobi preconditioned CG on the implicit Schur complement */
     SFMBA_SOLVER_DENSE = 2 /* explicit Schur complement + fp64 MFMA blocked Cholesky */
 };

@@ -235,9 +235,10 @@ struct sfmba_handle {
     DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
     DBuf<double> pair_part, Bsum, Sfull;
     // dense Cholesky solver
-    bool use_dense = false;
+    bool use_dense = false;      // dense Cholesky asked for
+    bool dense_allowed = false;  // small enough for the dense fallback
     int dense_n = 0;
-    DBuf<double> denseA, denseLinv;
+    DBuf<double> denseA, denseLinv, denseWork;
     DBuf<int> dense_fail;
     int dense_fallbacks = 0;
     int cur = 0;                           // index of the current parameter buffers
@@ -437,7 +438,7 @@ void schur_product(H* h, const double* x, const PcgState* state) {
 }
 
 // Block-Jacobi PCG on S dc = rhs; result in px.  Returns the iteration count.
-int phase_pcg(H* h, double lambda) {
+PcgState phase_pcg(H* h, double lambda) {
     const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
     const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     {
@@ -486,7 +487,7 @@ int phase_pcg(H* h, double lambda) {
         if (!pipelined) queue_batch(slot);
         else slot ^= 1;
     }
-    return st.iter;
+    return st;
 }
 
 // Dense path: scatter S into a dense array, factor it on the matrix cores, solve for the camera
@@ -497,7 +498,7 @@ bool phase_dense(H* h) {
     h->denseA.zero(h->stream);
     h->dense_fail.zero(h->stream);
     launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
-    launch_dense_cholesky_solve(h->denseA.p, n, n_real, h->denseLinv.p, h->dense_fail.p, h->rhs.p, h->px.p, h->stream);
+    launch_dense_cholesky_solve(h->denseA.p, n, n_real, h->denseLinv.p, h->denseWork.p, h->dense_fail.p, h->rhs.p, h->px.p, h->stream);
     int failed = 0;
     HIP_TRY(hipMemcpyAsync(&failed, h->dense_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -505,12 +506,29 @@ bool phase_dense(H* h) {
 }
 
 // Camera step of the damped normal equations into px; returns the PCG iteration count (0 = dense).
+// PCG is the default; the dense Cholesky runs when it was asked for, and as the fallback when PCG
+// ran out of iterations on a system small enough to factor (6 n_cameras <= dense_max_dim).
 int phase_linear_solve(H* h, double lambda) {
     if (h->use_dense) {
         if (phase_dense(h)) return 0;
         h->dense_fallbacks++;
     }
-    return phase_pcg(h, lambda);
+    const PcgState st = phase_pcg(h, lambda);
+    const bool converged = !(st.rz > st.tol2 * st.rz0);
+    if (!converged && !h->use_dense && h->dense_allowed && h->explicit_schur) {
+        if (h->denseA.n == 0) {
+            h->dense_n = dense_padded(6 * (int)h->n_cam);
+            h->denseA.alloc((size_t)h->dense_n * h->dense_n);
+            h->denseLinv.alloc((size_t)h->dense_n * 32);
+            h->denseWork.alloc((size_t)h->dense_n * 2);
+            h->dense_fail.alloc(1);
+        }
+        h->dense_fallbacks++;
+        if (phase_dense(h)) return st.iter;
+        // factorisation failed too: keep the PCG iterate (it is a descent direction)
+        (void)phase_pcg(h, lambda);
+    }
+    return st.iter;
 }
 
 // Step evaluation: back-substitution, retraction into the trial buffers, trial cost.
@@ -562,6 +580,7 @@ void do_solve(H* h, sfmba_stats* out) {
     double nu = 2.0;
     sfmba_stats st{};
     st.linear_solver = h->use_dense ? SFMBA_SOLVER_DENSE : SFMBA_SOLVER_PCG;
+    h->dense_fallbacks = 0;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
@@ -755,7 +774,8 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     int lin = h->opt.linear_solver;
     if (const char* e = getenv("SFMBA_LINEAR_SOLVER")) lin = atoi(e);
     const int dense_max = h->opt.dense_max_dim > 0 ? h->opt.dense_max_dim : 1536;
-    const bool want_dense = lin == SFMBA_SOLVER_DENSE || (lin == SFMBA_SOLVER_AUTO && 6 * (int64_t)n_cam <= dense_max);
+    const bool want_dense = lin == SFMBA_SOLVER_DENSE;
+    h->dense_allowed = lin == SFMBA_SOLVER_AUTO && 6 * (int64_t)n_cam <= dense_max;
     if (6 * (int64_t)n_cam > 16384 && lin == SFMBA_SOLVER_DENSE)
         fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)(6 * (int64_t)n_cam));
     h->use_dense = false;
@@ -879,6 +899,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         h->dense_n = dense_padded(6 * n_cam);
         h->denseA.alloc((size_t)h->dense_n * h->dense_n);
         h->denseLinv.alloc((size_t)h->dense_n * 32);
+        h->denseWork.alloc((size_t)h->dense_n * 2);
         h->dense_fail.alloc(1);
         h->use_dense = true;
     }

@@ -140,7 +140,7 @@ void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_dense.hip
 int dense_padded(int n_real);
-void launch_dense_cholesky_solve(double* A, int n, int n_real, double* Linv_all, int* fail,
+void launch_dense_cholesky_solve(double* A, int n, int n_real, double* Linv_all, double* work, int* fail,
                                  const double* b, double* x, hipStream_t st);
 
 }  // namespace sfmba

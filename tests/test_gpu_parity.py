@@ -187,6 +187,16 @@ def test_converged_cost_matches_scipy(name, solver):
     assert abs(st.final_cost - float(g["tight_cost"])) <= 1e-6 * float(g["tight_cost"])
 
 
+def test_dense_cholesky_is_the_fallback_when_pcg_runs_out_of_iterations():
+    g = load_golden("shuffled_9_200_700")
+    with make_engine(g, pcg_max_iter=1, pcg_rtol=1e-8) as eng:      # AUTO: PCG first
+        st = eng.solve()
+    assert st.linear_solver == 1 and st.n_dense > 0                 # steps re-solved by Cholesky
+    assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)
+    with make_engine(g) as eng:                                      # healthy PCG: no factorisation
+        assert eng.solve().n_dense == 0
+
+
 def test_inputs_are_not_modified_and_solve_is_deterministic():
     g = load_golden("rho2_11_300_600")
     keep = {k: g[k].copy() for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d")}
