@@ -372,7 +372,8 @@ void reduce_scalars(H* h, int first, int count) {
 
 // ---- solver phases ------------------------------------------------------------------------
 // Linearise at the current estimate: seeds, residuals, V_p, g_p, U_c, g_c.  Leaves the cost sum
-// in scalars[SLOT_COST] (this partition's part) and max|g_p| in scalars[SLOT_GMAX_PT].
+// in scalars[SLOT_COST] (this partition's part), max|g_p| in scalars[SLOT_GMAX_PT] and max|g_c|
+// in scalars[SLOT_GMAX_CAM].  (Running the two halves on two streams was measured: no gain.)
 void phase_linearize(H* h) {
     Scope t(h, F_LIN);
     refresh_dev(h);
@@ -380,6 +381,7 @@ void phase_linearize(H* h) {
     launch_lin_cm(h->dev, h->stream);
     launch_chunk_reduce(h->dev, 27, h->UG.p, h->stream);
     allreduce(h, h->UG.p, (size_t)h->n_cam * 27);
+    launch_gmax_cam(h->dev, h->stream);
     h->linearized = false;
 }
 
@@ -390,10 +392,12 @@ void phase_damp(H* h, double lambda) {
         {
             Scope t(h, F_DAMP);
             launch_damp_pm(h->dev, lambda, h->stream);
+        }
+        {
+            Scope t(h, F_DAMP);
             launch_spmv_cm(h->dev, h->s0.p, nullptr, h->stream);         // sum W Vinv g_p
             launch_chunk_reduce(h->dev, 6, h->qS.p, h->stream);
         }
-        allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
         {
             Scope t(h, F_SCHUR);
             {
@@ -402,11 +406,11 @@ void phase_damp(H* h, double lambda) {
             }
             launch_block_reduce(h->dev, h->stream);
         }
+        allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
         allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36);
         {
             Scope t(h, F_SCHUR);
             launch_schur_finish(h->dev, lambda, h->qS.p, h->stream);
-            launch_finalize_gmax_cam(h->dev, h->stream);
         }
     } else {
         Scope t(h, F_DAMP);
@@ -592,25 +596,18 @@ void do_solve(H* h, sfmba_stats* out) {
     reduce_scalars(h, SLOT_COST, 1);
     read_scalars(h, sc);
     double cost = 0.5 * sc[SLOT_COST];
-    double gmax_pt = gather_gmax_pt(h, sc[SLOT_GMAX_PT]);
+    double g_norm = std::max(sc[SLOT_GMAX_CAM], gather_gmax_pt(h, sc[SLOT_GMAX_PT]));
     st.nfev = 1;
     st.initial_cost = cost;
     if (!std::isfinite(cost)) fail(SFMBA_ERR_NONFINITE, "Residuals are not finite in the initial point.");
     int status = -1;
-    double g_norm = 0.0, step_norm = 0.0, actual = 0.0;
-    bool fresh = true;     // a linearisation not yet tested against gtol
-    if (o.verbose >= 2 && o.rank <= 0) print_header();
+    double step_norm = 0.0, actual = 0.0;
+    const bool talk = o.verbose >= 2 && o.rank <= 0;
+    if (talk) { print_header(); print_row(0, st.nfev, cost, actual, step_norm, g_norm, true); }
     int accepted = 0;
+    if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
     for (int it = 0; it < max_it && status < 0; ++it) {
         phase_damp(h, lambda);
-        if (fresh) {
-            read_scalars(h, sc);
-            g_norm = std::max(sc[SLOT_GMAX_CAM], gmax_pt);
-            fresh = false;
-            if (o.verbose >= 2 && o.rank <= 0) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, accepted == 0);
-            if (g_norm < gtol) { status = SFMBA_STATUS_GTOL; break; }
-            if (st.nfev >= max_nfev) { status = SFMBA_STATUS_MAX_NFEV; break; }
-        }
         st.pcg_iterations += phase_linear_solve(h, lambda);
         phase_trial(h, nullptr);
         read_scalars(h, sc);
@@ -633,15 +630,15 @@ void do_solve(H* h, sfmba_stats* out) {
             lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-15);
             nu = 2.0;
             cost = cost_new;
-            phase_linearize(h);
+            phase_linearize(h);          // also the gradient norm at the new iterate
             st.njev++;
-            reduce_scalars(h, SLOT_COST, 1);
             read_scalars(h, sc);
-            gmax_pt = gather_gmax_pt(h, sc[SLOT_GMAX_PT]);
-            fresh = true;
+            g_norm = std::max(sc[SLOT_GMAX_CAM], gather_gmax_pt(h, sc[SLOT_GMAX_PT]));
+            if (talk) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, false);
             if (ft && xt) status = SFMBA_STATUS_FTOL_XTOL;
             else if (ft) status = SFMBA_STATUS_FTOL;
             else if (xt) status = SFMBA_STATUS_XTOL;
+            else if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
         } else {
             lambda *= nu;
             nu *= 2.0;
@@ -650,12 +647,6 @@ void do_solve(H* h, sfmba_stats* out) {
         if (status < 0 && st.nfev >= max_nfev) status = SFMBA_STATUS_MAX_NFEV;
     }
     if (status < 0) status = SFMBA_STATUS_MAX_NFEV;
-    if (fresh) {   // gradient norm at the final iterate
-        phase_damp(h, lambda);
-        read_scalars(h, sc);
-        g_norm = std::max(sc[SLOT_GMAX_CAM], gmax_pt);
-        if (o.verbose >= 2 && o.rank <= 0) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, accepted == 0);
-    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     auto t1 = std::chrono::steady_clock::now();
     if (h->profile) collect_spans(h);

@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kBlock) void k_precond(Dev d, double lambda) {
             gmax = fmax(gmax, fabs(g[i]));
         }
     }
-    double m = block_max(gmax, red);
-    if (threadIdx.x == 0) put_partial(d, SLOT_GMAX_CAM, m);
+    (void)gmax;
+    (void)red;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -535,6 +535,21 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
     if (threadIdx.x == 0) d.scalars[slot] = r;
 }
 
+// max |g_c| over the cameras (after the all-reduce of UG).
+__global__ __launch_bounds__(kBlock) void k_gmax_cam(Dev d) {
+    __shared__ double red[16];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double g = 0.0;
+    if (i < d.n_cam * 6) g = fabs(d.UG[27 * (size_t)(i / 6) + 21 + (i % 6)]);
+    const double m = block_max(g, red);
+    if (threadIdx.x == 0) put_partial(d, SLOT_GMAX_CAM, m);
+}
+void launch_gmax_cam(const Dev& d, hipStream_t st) {
+    const int nb = cdiv(d.n_cam * 6, kBlock);
+    hipLaunchKernelGGL(k_gmax_cam, dim3(nb), dim3(kBlock), 0, st, d);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, nb, 1u);
+}
+
 // a += b (in-process all-reduce of several handles)
 __global__ __launch_bounds__(kBlock) void k_vec_add(double* __restrict__ a, const double* __restrict__ b, size_t n) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -581,10 +596,6 @@ void launch_sdiag_cm(const Dev& d, hipStream_t st) {
 }
 void launch_precond(const Dev& d, double lambda, hipStream_t st) {
     hipLaunchKernelGGL(k_precond, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
-}
-void launch_finalize_gmax_cam(const Dev& d, hipStream_t st) {
-    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, blocks_cam(d), 1u);
 }
 void launch_spmv_pm(const Dev& d, const double* x, const PcgState* state, hipStream_t st) {
     if (d.n_wtiles == 0) return;
