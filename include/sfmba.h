@@ -156,6 +156,13 @@ int sfmba_solve(sfmba_handle* h, sfmba_stats* stats);
  * poses n_cameras x 12 (orthonormal rotation block + translation), points n_points x 3. */
 int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d);
 
+/* Mean reprojection error |projection - observation| (pixels) of every camera at the current
+ * estimate and, optionally, its observation count: what ImageView.reproject_view() prints per
+ * view after each bundle adjustment (/root/reference/view.py:103-119 with
+ * utils.calculate_reprojection_error, utils.py:337-352; main.py:123).  A camera without
+ * observations gets NaN, as np.mean([]) does. */
+int sfmba_reprojection_errors(sfmba_handle* h, double* mean_error, int64_t* n_observations);
+
 /* ---- diagnostics used by the parity tests: one linearisation at the current estimate ---- */
 
 /* Linearise and damp with lambda.  Afterwards the blocks below can be read. */

@@ -21,7 +21,6 @@ from .engine import Engine, TERMINATION_MESSAGES
 
 __all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment"]
 
-_ZERO_2D = {}
 _fun_cache = {"key": None, "engine": None, "keep": None}
 
 
@@ -124,6 +123,8 @@ class BundleAdjustment:
         self.max_nfev, self.verbose = max_nfev, verbose
         self.engine_options = engine_options
         self.result = None
+        self.reprojection_error = None      # per view, filled by optimize()
+        self.reprojection_count = None
 
     def view2idx(self):
         """
@@ -178,6 +179,9 @@ class BundleAdjustment:
             stats = eng.solve()
             t1 = time.time()
             poses, points_3d = eng.get_params()
+            # per-view mean reprojection error at the optimum (what main.py:123 prints per view
+            # through ImageView.reproject_view), computed where the data already is
+            self.reprojection_error, self.reprojection_count = eng.reprojection_errors()
         logging.info(f"Optimized {self.n_points} in {t1-t0} seconds.")
         self.result = stats.as_dict()
         self.result["message"] = TERMINATION_MESSAGES[stats.status]

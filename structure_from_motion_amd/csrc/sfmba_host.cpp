@@ -1223,6 +1223,26 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
     });
 }
 
+int sfmba_reprojection_errors(sfmba_handle* h, double* mean_error, int64_t* n_observations) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_reprojection_errors");
+        if (!mean_error) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_reprojection_errors: null output");
+        refresh_dev(h);
+        const size_t n = (size_t)h->n_cam * 2;
+        launch_reproj_cm(h->dev, h->tmp_b.p, h->stream);      // tmp_b holds >= 36 n_cam doubles
+        allreduce(h, h->tmp_b.p, n);
+        std::vector<double> v(n);
+        HIP_TRY(hipMemcpyAsync(v.data(), h->tmp_b.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int64_t c = 0; c < h->n_cam; ++c) {
+            const double cnt = v[2 * c + 1];
+            mean_error[c] = cnt > 0 ? v[2 * c] / cnt : std::numeric_limits<double>::quiet_NaN();   // np.mean([]) is nan
+            if (n_observations) n_observations[c] = (int64_t)cnt;
+        }
+        h->linearized = false;      // chunk_part was reused
+    });
+}
+
 int sfmba_linearize(sfmba_handle* h, double lambda) {
     return guarded(h, [&] {
         need_problem(h, "sfmba_linearize");

@@ -128,6 +128,7 @@ void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t 
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
 void launch_cost_pm(const Dev& d, hipStream_t st);
 void launch_gmax_cam(const Dev& d, hipStream_t st);
+void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st);   // [n_cam][2] = (sum of errors, count)
 int scal_blocks_pt(const Dev& d);
 void launch_vec_add(double* a, const double* b, size_t n, hipStream_t st);
 int blocks_cam(const Dev& d);

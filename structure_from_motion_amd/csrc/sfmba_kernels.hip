@@ -17,6 +17,7 @@
 namespace sfmba {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kBlock / 64); }
 
 // Store one block partial of a scalar slot.
 __device__ __forceinline__ void put_partial(const Dev& d, int slot, double v) {
@@ -535,6 +536,37 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
     if (threadIdx.x == 0) d.scalars[slot] = r;
 }
 
+// Per-camera sum of reprojection errors |projection - observation| at the current estimate,
+// camera-major: chunk partials (sum, count).  The per-view quantity the reference prints after
+// every bundle adjustment (/root/reference/view.py:103-119, utils.py:337-352).
+__global__ __launch_bounds__(kBlock) void k_reproj_cm(Dev d) {
+    const int lane = threadIdx.x & 63;
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_chunks) return;
+    const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
+    const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
+    const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
+    const Cam cam = load_cam(d.cams, c);
+    double sum = 0.0;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        const double4 X = d.X[d.cm_pt[k]];
+        const Seed s = project_seed(cam, X.x, X.y, X.z);
+        const double2 uv = d.cm_uv[k];
+        double ru, rv;
+        residual(s, d.K, uv.x, uv.y, ru, rv);
+        sum += sqrt(ru * ru + rv * rv);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) {
+        d.chunk_part[2 * (size_t)q] = sum;
+        d.chunk_part[2 * (size_t)q + 1] = (double)(k1 - k0);
+    }
+}
+void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st) {
+    if (d.n_chunks > 0) hipLaunchKernelGGL(k_reproj_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d);
+    launch_chunk_reduce(d, 2, out2, st);
+}
+
 // max |g_c| over the cameras (after the all-reduce of UG).
 __global__ __launch_bounds__(kBlock) void k_gmax_cam(Dev d) {
     __shared__ double red[16];
@@ -564,7 +596,7 @@ int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
 static int blocks_wtile(const Dev& d) { return cdiv(d.n_wtiles, kBlock / 64); }
 static int blocks_obs(const Dev& d) { return cdiv(d.n_obs, kBlock); }
 int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
-static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kBlock / 64); }
+
 
 void launch_residuals(const Dev& d, double* out, hipStream_t st) {
     if (d.n_obs == 0) return;

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmba.s
 EXPORTS = (
     "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error",
     "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
-    "sfmba_solve", "sfmba_get_params", "sfmba_linearize", "sfmba_get_blocks",
+    "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_linearize", "sfmba_get_blocks",
     "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_solve_step",
     "sfmba_comm_unique_id", "sfmba_comm_init",
     "sfmba_local_group_create", "sfmba_local_group_destroy", "sfmba_comm_init_local",
@@ -101,6 +101,7 @@ def load_library(path=None):
     lib.sfmba_jacobian_blocks.argtypes = [vp, dp, dp]
     lib.sfmba_solve.argtypes = [vp, C.POINTER(Stats)]
     lib.sfmba_get_params.argtypes = [vp, dp, dp]
+    lib.sfmba_reprojection_errors.argtypes = [vp, dp, ip]
     lib.sfmba_linearize.argtypes = [vp, C.c_double]
     lib.sfmba_get_blocks.argtypes = [vp, dp, dp, dp, dp]
     lib.sfmba_schur_matvec.argtypes = [vp, dp, dp]
@@ -232,6 +233,13 @@ class Engine:
         st = Stats()
         self._check(self._lib.sfmba_solve(self._h, C.byref(st)))
         return st
+
+    def reprojection_errors(self):
+        """(mean reprojection error per camera, observation count per camera) at the current estimate."""
+        mean = np.empty(self.n_cameras)
+        cnt = np.zeros(self.n_cameras, dtype=np.int64)
+        self._check(self._lib.sfmba_reprojection_errors(self._h, _dp(mean), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+        return mean, cnt
 
     # -- diagnostics
     def linearize(self, lam):

@@ -57,6 +57,14 @@ def test_optimize_matches_reference_contract(tmp_path, monkeypatch, capsys, capl
     ref = o.solve_reference(p)
     assert b.result["final_cost"] <= ref["cost"] * (1 + 1e-6)
     assert abs(o.cost(p, poses, points_3d) - b.result["final_cost"]) <= 1e-9 * b.result["final_cost"]
+    # per-view mean reprojection error, as ImageView.reproject_view computes it (view.py:103-119)
+    f = o.fun(np.hstack((poses.ravel(), points_3d.ravel())), 6, 120, p["camera_indices"],
+              p["point_indices"], p["points_2d"], p["K"]).reshape(-1, 2)
+    err = np.linalg.norm(f, axis=1)
+    for j in range(6):
+        sel = p["camera_indices"] == j
+        assert b.reprojection_count[j] == sel.sum()
+        assert abs(b.reprojection_error[j] - err[sel].mean()) <= 1e-10 * err[sel].mean()
 
 
 def test_unknown_view_id_raises_key_error(tmp_path, monkeypatch):
