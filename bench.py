@@ -166,8 +166,15 @@ def main():
             return ab[f] / avg_s / 1e9 if avg_s > 0 else 0.0
 
         kernel_name = {"pairs": "k_schur_pairs", "bsr": "k_pcg_spmv_bsr", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm"}
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+        # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0:
+            with open(tpath) as f:
+                traffic = json.load(f).get("kernels", {}).get(kernel_name[dom], {}).get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "kernel": kernel_name[dom], "achieved": price(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": price(dom) / HBM_PEAK_GBS, "traffic": None,
+                "frac": price(dom) / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": families[dom]["avg_us"],
                 "launches_per_solve": families[dom]["effective_launches"],
                 "other_kernels": {kernel_name[f]: {"algorithmic_bytes_per_launch": ab[f],
