@@ -141,9 +141,10 @@ __device__ __forceinline__ void spd3_inverse(const double* a, double* inv) {
     inv[5] = i22 * i22;
 }
 
-// In-register Cholesky inverse of a symmetric positive definite 6x6 (full storage, row-major).
-// Returns false when a pivot is not positive; A is destroyed, Ainv receives the full inverse.
-__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6]) {
+// In-register Cholesky of a symmetric positive definite 6x6 (full storage, row-major): A = L L'.
+// Returns false when a pivot is not positive; A is destroyed, the lower triangle of Li receives
+// L^-1 (the strict upper triangle is left untouched).
+__device__ __forceinline__ bool spd6_chol_linv(double (&A)[6][6], double (&Li)[6][6]) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -161,8 +162,7 @@ __device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6
             A[i][j] = v * il;
         }
     }
-    // Linv (lower) by forward substitution, stored in the lower triangle of Ainv.
-    double Li[6][6];
+    // Linv (lower) by forward substitution
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         Li[j][j] = 1.0 / A[j][j];
@@ -174,6 +174,13 @@ __device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6
             Li[i][j] = v / A[i][i];
         }
     }
+    return ok;
+}
+
+// Inverse of a symmetric positive definite 6x6 through its Cholesky factor: Ainv = Li' Li.
+// Returns false when a pivot is not positive; A is destroyed.
+__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6], double (&Li)[6][6]) {
+    const bool ok = spd6_chol_linv(A, Li);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -185,6 +192,10 @@ __device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6
             Ainv[j][i] = v;
         }
     return ok;
+}
+__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6]) {
+    double Li[6][6];
+    return spd6_inverse(A, Ainv, Li);
 }
 
 // exp([w]x) as a row-major 3x3.

@@ -234,6 +234,12 @@ struct sfmba_handle {
     DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, pchunk_blk, pchunk_beg;
     DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
     DBuf<double> pair_part, Bsum, Sfull;
+    // single-launch PCG on the scaled system
+    bool fused_pcg = false;
+    int fused_blocks = 0, fused_fallbacks = 0;
+    DBuf<double> Shat, Fscale, bhat, fvec;    // fvec: r[2], w[2], s[2], p, xh
+    DBuf<double2> fdots;
+    FusedPcg fused{};
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
     bool dense_allowed = false;  // small enough for the dense fallback
@@ -411,6 +417,7 @@ void phase_damp(H* h, double lambda) {
         {
             Scope t(h, F_SCHUR);
             launch_schur_finish(h->dev, lambda, h->qS.p, h->stream);
+            if (h->fused_pcg) launch_schur_scale(h->dev, h->fused, h->stream);
         }
     } else {
         Scope t(h, F_DAMP);
@@ -445,6 +452,28 @@ void schur_product(H* h, const double* x, const PcgState* state) {
 PcgState phase_pcg(H* h, double lambda) {
     const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
     const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
+    if (h->explicit_schur && h->fused_pcg) {
+        // the whole solve in one cooperative launch; a breakdown of the single-reduction
+        // recurrence or a barrier timeout falls through to the launch-per-iteration solver
+        FusedPcg& f = h->fused;
+        f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = max_iter;
+        hipError_t e;
+        {
+            Scope t(h, F_BSR);
+            e = launch_pcg_fused(f, h->fused_blocks, h->stream);
+        }
+        if (e == hipSuccess) {
+            HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            const PcgState st = h->pcg_host[0];
+            if (getenv("SFMBA_PCG_TRACE")) fprintf(stderr, "pcg fused: %d iterations, %.2f us in kernel, flag %d\n", st.iter, st.ticks * 0.01, st.pad);
+            if (st.pad == 0) return st;
+        } else {
+            (void)hipGetLastError();
+            h->fused_pcg = false;               // cooperative launch not available: do not try again
+        }
+        h->fused_fallbacks++;
+    }
     {
         Scope t(h, F_PCGVEC);
         launch_pcg_init(h->dev, tol, max_iter, h->stream);
@@ -886,6 +915,35 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     HIP_TRY(hipStreamSynchronize(st));
     h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
     h->explicit_schur = true;
+    // single-launch PCG: one workgroup per compute unit at most, every workgroup co-resident
+    int fused = 1;
+    if (const char* e = getenv("SFMBA_PCG_FUSED")) fused = atoi(e);
+    h->fused_pcg = false;
+    if (fused && !want_dense) {
+        const int cap = pcg_fused_max_blocks(h->device);
+        const int rows = pcg_fused_rows_per_block();
+        int blocks = std::min(cap, (n_cam + rows - 1) / rows);
+        if (const char* e = getenv("SFMBA_PCG_FUSED_BLOCKS")) blocks = std::min(blocks, std::max(1, atoi(e)));
+        if (blocks > 0) {
+            const size_t v = (size_t)n_cam * 6;
+            h->Shat.alloc((size_t)nnzb * 36);
+            h->Fscale.alloc((size_t)n_cam * 36);
+            h->bhat.alloc(v);
+            h->fvec.alloc(8 * v);
+            h->fdots.alloc((pcg_fused_record_words(blocks) + 1) / 2);
+            FusedPcg& f = h->fused;
+            f.n_cam = n_cam;
+            f.bsr_ptr = h->bsr_ptr.p; f.bsr_col = h->bsr_col.p;
+            f.Shat = h->Shat.p; f.F = h->Fscale.p; f.bhat = h->bhat.p;
+            double* b = h->fvec.p;
+            f.r[0] = b; f.r[1] = b + v; f.w[0] = b + 2 * v; f.w[1] = b + 3 * v;
+            f.s[0] = b + 4 * v; f.s[1] = b + 5 * v; f.p = b + 6 * v; f.xh = b + 7 * v;
+            f.dots = h->fdots.p;
+            f.timeout_ticks = 20000000LL;         // 0.2 s of the 100 MHz wall clock
+            h->fused_blocks = blocks;
+            h->fused_pcg = true;
+        }
+    }
     if (want_dense) {
         h->dense_n = dense_padded(6 * n_cam);
         h->denseA.alloc((size_t)h->dense_n * h->dense_n);

@@ -36,6 +36,27 @@ struct PcgState {
     int max_iter;
     int done;
     int pad;
+    long long ticks;  // single-launch solver: duration in ticks of the 100 MHz wall clock
+};
+
+// Arguments of the single-launch PCG (k_pcg_fused): the symmetrically scaled system
+// Shat = F S F', bhat = F rhs with F = L^-1 of the diagonal blocks (S_cc = L L'), so that the
+// block-Jacobi preconditioner becomes the identity and x = F' xhat.
+struct FusedPcg {
+    int n_cam;
+    const int* bsr_ptr; const int* bsr_col;
+    const double* Shat;       // [nnzb][36]
+    const double* F;          // [n_cam][36] lower triangular, row-major
+    const double* bhat;       // [n_cam][6]
+    double* r[2]; double* w[2]; double* s[2];   // [n_cam][6] each, double-buffered by iteration parity
+    double* p; double* xh;    // [n_cam][6]
+    double* x;                // [n_cam][6] solution of the unscaled system
+    double2* dots;            // [3][gridDim.x] per-workgroup (r'r, w'r) records in rotating slots,
+                              // then one abort word; all bits set = not written / no abort
+    PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout
+    double tol2;
+    int max_iter;
+    long long timeout_ticks;  // of the 100 MHz wall clock
 };
 
 // Everything a kernel needs, passed by value.  "pm" arrays are in point-major observation
@@ -123,6 +144,11 @@ void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st);            // e
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);                 // implicit mode: direction only
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);    // implicit mode: q = U* p - qS
 void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
+// whole PCG solve in one cooperative launch (explicit mode); returns the launch error
+int pcg_fused_max_blocks(int device);
+int pcg_fused_rows_per_block();
+size_t pcg_fused_record_words(int blocks);
+hipError_t launch_pcg_fused(const FusedPcg& f, int blocks, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
@@ -137,6 +163,8 @@ int bsr_blocks(const Dev& d);
 void launch_schur_pairs(const Dev& d, hipStream_t st);
 void launch_block_reduce(const Dev& d, hipStream_t st);
 void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st);
+// scaled system for the single-launch PCG: F, bhat, Shat; also clears the barrier words
+void launch_schur_scale(const Dev& d, const FusedPcg& f, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_dense.hip

@@ -175,7 +175,67 @@ __global__ __launch_bounds__(kBlock) void k_bsr_to_dense(Dev d, double* __restri
     A[(size_t)row * n + col] = d.Sfull[t];
 }
 
+// F = L^-1 of every diagonal block (S_cc = L L') and bhat = F rhs; one thread per camera.
+__global__ __launch_bounds__(kBlock) void k_scale_factors(Dev d, FusedPcg f) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= d.n_cam) return;
+    const double* S = d.Sfull + 36 * (size_t)d.bsr_diag[c];
+    double A[6][6], Li[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { A[i][j] = 0.5 * (S[6 * i + j] + S[6 * j + i]); Li[i][j] = 0.0; }
+    double dg[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dg[i] = A[i][i];
+    const bool ok = spd6_chol_linv(A, Li);
+    double* o = const_cast<double*>(f.F) + 36 * (size_t)c;
+    double b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = d.rhs[6 * (size_t)c + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double lij = ok ? (j <= i ? Li[i][j] : 0.0) : (i == j ? 1.0 / sqrt(fmax(fabs(dg[i]), 1e-300)) : 0.0);
+            o[6 * i + j] = lij;
+            v += lij * b[j];
+        }
+        const_cast<double*>(f.bhat)[6 * (size_t)c + i] = v;
+    }
+}
+
+// Shat_b = F_row S_b F_col'; one thread per (block, element).
+__global__ __launch_bounds__(kBlock) void k_scale_blocks(Dev d, FusedPcg f) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= d.nnzb * 36) return;
+    const int b = t / 36, e = t - 36 * b, i = e / 6, j = e - 6 * i;
+    int lo = 0, hi = d.n_cam;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (d.bsr_ptr[mid] <= b) lo = mid; else hi = mid;
+    }
+    const double* Fi = f.F + 36 * (size_t)lo + 6 * i;
+    const double* Fj = f.F + 36 * (size_t)d.bsr_col[b] + 6 * j;
+    const double* S = d.Sfull + 36 * (size_t)b;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double tk = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) tk += S[6 * k + l] * Fj[l];
+        v += Fi[k] * tk;
+    }
+    const_cast<double*>(f.Shat)[t] = v;
+}
+
 int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerBlock); }
+
+void launch_schur_scale(const Dev& d, const FusedPcg& f, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale_factors, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, f);
+    hipLaunchKernelGGL(k_scale_blocks, dim3(cdiv(d.nnzb * 36, kBlock)), dim3(kBlock), 0, st, d, f);
+}
 
 void launch_schur_pairs(const Dev& d, hipStream_t st) {
     if (d.n_pchunks > 0)
