@@ -76,6 +76,11 @@ typedef struct sfmba_options {
      * (equal observation counts).  nranks <= 1 means the whole problem. */
     int32_t rank;
     int32_t nranks;
+    /* PCG on the explicit reduced matrix: 0 = choose (single launch when the device supports
+     * cooperative launches), 1 = two launches per iteration, 2 = the whole solve in one
+     * cooperative launch (falls back to 1 per solve on a breakdown of its recurrence). */
+    int32_t pcg_mode;
+    int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
 } sfmba_options;
 
 typedef struct sfmba_stats {
@@ -107,6 +112,8 @@ typedef struct sfmba_stats {
     int64_t schur_pairs;                       /* observation pairs per assembly (explicit mode) */
     int64_t schur_blocks;                      /* 6x6 blocks of the reduced matrix (explicit mode) */
     int64_t schur_chunks;                      /* wavefront-sized pair chunks per assembly */
+    int64_t pcg_single_launch;                 /* linear solves done by the single-launch PCG */
+    int64_t pcg_single_fallbacks;              /* single-launch solves redone launch by launch */
 } sfmba_stats;
 
 /* Fill *opts with the defaults listed above. */

@@ -236,9 +236,11 @@ struct sfmba_handle {
     DBuf<double> pair_part, Bsum, Sfull;
     // single-launch PCG on the scaled system
     bool fused_pcg = false;
-    int fused_blocks = 0, fused_fallbacks = 0;
-    DBuf<double> Shat, Fscale, bhat, fvec;    // fvec: r[2], w[2], s[2], p, xh
+    int fused_blocks = 0;
+    int64_t fused_solves = 0, fused_fallbacks = 0;
+    DBuf<double> Shat, Fscale, bhat, fvec;    // fvec: generation records, p, xh
     DBuf<double2> fdots;
+    bool trace_pcg = false;
     FusedPcg fused{};
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
@@ -466,8 +468,9 @@ PcgState phase_pcg(H* h, double lambda) {
             HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             const PcgState st = h->pcg_host[0];
-            if (getenv("SFMBA_PCG_TRACE")) fprintf(stderr, "pcg fused: %d iterations, %.2f us in kernel, flag %d\n", st.iter, st.ticks * 0.01, st.pad);
-            if (st.pad == 0) return st;
+            if (h->trace_pcg)
+                fprintf(stderr, "pcg single launch: %d iterations, %.2f us in kernel, flag %d\n", st.iter, st.ticks * 0.01, st.pad);
+            if (st.pad == 0) { h->fused_solves++; return st; }
         } else {
             (void)hipGetLastError();
             h->fused_pcg = false;               // cooperative launch not available: do not try again
@@ -614,6 +617,7 @@ void do_solve(H* h, sfmba_stats* out) {
     sfmba_stats st{};
     st.linear_solver = h->use_dense ? SFMBA_SOLVER_DENSE : SFMBA_SOLVER_PCG;
     h->dense_fallbacks = 0;
+    h->fused_solves = h->fused_fallbacks = 0;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
@@ -699,6 +703,7 @@ void do_solve(H* h, sfmba_stats* out) {
     st.schur_blocks = h->explicit_schur ? h->nnzb : 0;
     st.schur_chunks = h->explicit_schur ? h->n_pchunks : 0;
     st.ms_pairs = h->fam_ms[F_PAIRS]; st.n_pairs = h->fam_n[F_PAIRS];
+    st.pcg_single_launch = h->fused_solves; st.pcg_single_fallbacks = h->fused_fallbacks;
     if (o.verbose >= 1 && o.rank <= 0) {
         static const char* msg[] = {"The maximum number of function evaluations is exceeded.",
                                     "`gtol` termination condition is satisfied.",
@@ -916,29 +921,30 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
     h->explicit_schur = true;
     // single-launch PCG: one workgroup per compute unit at most, every workgroup co-resident
-    int fused = 1;
-    if (const char* e = getenv("SFMBA_PCG_FUSED")) fused = atoi(e);
+    int pcg_mode = h->opt.pcg_mode;
+    if (const char* e = getenv("SFMBA_PCG_MODE")) pcg_mode = atoi(e);
     h->fused_pcg = false;
-    if (fused && !want_dense) {
+    if (pcg_mode != 1 && !want_dense) {
         const int cap = pcg_fused_max_blocks(h->device);
         const int rows = pcg_fused_rows_per_block();
         int blocks = std::min(cap, (n_cam + rows - 1) / rows);
-        if (const char* e = getenv("SFMBA_PCG_FUSED_BLOCKS")) blocks = std::min(blocks, std::max(1, atoi(e)));
+        if (h->opt.pcg_blocks > 0) blocks = std::min(blocks, h->opt.pcg_blocks);
+        if (const char* e = getenv("SFMBA_PCG_BLOCKS")) blocks = std::min(blocks, std::max(1, atoi(e)));
         if (blocks > 0) {
             const size_t v = (size_t)n_cam * 6;
             h->Shat.alloc((size_t)nnzb * 36);
             h->Fscale.alloc((size_t)n_cam * 36);
             h->bhat.alloc(v);
-            h->fvec.alloc(8 * v);
+            h->fvec.alloc(pcg_fused_vector_words(n_cam) + 2 * v);
             h->fdots.alloc((pcg_fused_record_words(blocks) + 1) / 2);
             FusedPcg& f = h->fused;
             f.n_cam = n_cam;
-            f.bsr_ptr = h->bsr_ptr.p; f.bsr_col = h->bsr_col.p;
+            f.bsr_ptr = h->bsr_ptr.p; f.bsr_col = h->bsr_col.p; f.bsr_diag = h->bsr_diag.p;
             f.Shat = h->Shat.p; f.F = h->Fscale.p; f.bhat = h->bhat.p;
-            double* b = h->fvec.p;
-            f.r[0] = b; f.r[1] = b + v; f.w[0] = b + 2 * v; f.w[1] = b + 3 * v;
-            f.s[0] = b + 4 * v; f.s[1] = b + 5 * v; f.p = b + 6 * v; f.xh = b + 7 * v;
+            f.vec = h->fvec.p;
+            f.p = f.vec + pcg_fused_vector_words(n_cam); f.xh = f.p + v;
             f.dots = h->fdots.p;
+            h->trace_pcg = getenv("SFMBA_PCG_TRACE") != nullptr;
             f.timeout_ticks = 20000000LL;         // 0.2 s of the 100 MHz wall clock
             h->fused_blocks = blocks;
             h->fused_pcg = true;
@@ -1141,6 +1147,7 @@ void sfmba_default_options(sfmba_options* o) {
     o->max_iterations = 200; o->initial_lambda = 1e-4; o->pcg_rtol = 0.1; o->pcg_max_iter = 1000;
     o->linear_solver = SFMBA_SOLVER_AUTO; o->dense_max_dim = 1536; o->verbose = 0; o->profile = 0; o->device = -1;
     o->rank = 0; o->nranks = 1;
+    o->pcg_mode = 0; o->pcg_blocks = 0;
 }
 
 int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {

@@ -44,14 +44,14 @@ struct PcgState {
 // block-Jacobi preconditioner becomes the identity and x = F' xhat.
 struct FusedPcg {
     int n_cam;
-    const int* bsr_ptr; const int* bsr_col;
+    const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;
     const double* Shat;       // [nnzb][36]
     const double* F;          // [n_cam][36] lower triangular, row-major
     const double* bhat;       // [n_cam][6]
-    double* r[2]; double* w[2]; double* s[2];   // [n_cam][6] each, double-buffered by iteration parity
-    double* p; double* xh;    // [n_cam][6]
+    double* vec;              // [4][n_cam][18] (r, w, s) records in rotating generation slots
+    double* p; double* xh;    // [n_cam][6], touched by the owning wavefront only
     double* x;                // [n_cam][6] solution of the unscaled system
-    double2* dots;            // [3][gridDim.x] per-workgroup (r'r, w'r) records in rotating slots,
+    double2* dots;            // [4][gridDim.x] per-workgroup (r'r, w'r) records in rotating slots,
                               // then one abort word; all bits set = not written / no abort
     PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout
     double tol2;
@@ -148,6 +148,7 @@ void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
 int pcg_fused_max_blocks(int device);
 int pcg_fused_rows_per_block();
 size_t pcg_fused_record_words(int blocks);
+size_t pcg_fused_vector_words(int n_cam);
 hipError_t launch_pcg_fused(const FusedPcg& f, int blocks, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);

@@ -216,31 +216,43 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_
 // Conjugate gradients on the scaled system Shat xhat = bhat (block-Jacobi preconditioning folded
 // into the matrix), in the single-reduction form of Chronopoulos and Gear:
 //     gamma = r'r, delta = w'r (w = Shat r);  beta = gamma / gamma_prev;
-//     alpha = gamma / (delta - beta gamma / alpha_prev)
+//     alpha = gamma / (delta - beta gamma / alpha_prev)   [= gamma / (delta - beta^2 den_prev)]
 //     p = r + beta p;  s = w + beta s;  xhat += alpha p;  r -= alpha s;  w = Shat r
-// so that one exchange between the workgroups per iteration is enough: every workgroup adds the
-// same per-workgroup (gamma, delta) records in the same order, gets the same alpha and beta,
-// updates the rows it owns and, for every column its rows gather, rebuilds that column's new r
-// from the previous r, w and s (three reads instead of a second exchange).  r, w and s are
-// double-buffered by iteration parity; p and xhat are only touched by their owner.  One
-// wavefront per camera row at a time, one lane per 6x6 block of the row, so that the gather of a
-// row is a single round trip to memory.
+// Every workgroup adds the same per-workgroup (gamma, delta) records in the same order, gets the
+// same alpha and beta, updates the rows it owns and, for every column its rows gather, rebuilds
+// that column's new r from the column's previous (r, w, s) record; p and xhat are only touched
+// by their owner.  One wavefront per camera row at a time, one lane per 6x6 block of the row;
+// the first row of a wavefront (its blocks, columns and own vectors) stays in registers.
 //
-// The exchange is also the grid barrier.  Records live in three rotating slots that hold a
-// sentinel (all bits set) until written: workgroup B publishes its record of iteration k in
-// slot k % 3 after all its vector stores have been acknowledged, thread i of every workgroup
-// polls the record of workgroup i until it is no sentinel, and once B has collected all records
-// of iteration k it re-arms its record in slot (k + 2) % 3 (last read at iteration k - 1, which
-// everybody has left by then).  No atomic
-// read-modify-write and no cache write-back or invalidation is involved: everything another
-// workgroup reads within the launch moves through agent-scope relaxed loads and stores, which
-// go past the caches that are not coherent between the dies, and the matrix stays in L2.
+// Synchronisation is by data flow, there is no grid barrier.  What iteration k produces - the
+// (r, w, s) record of every camera and the (gamma, delta) record of every workgroup, together
+// "generation k" - goes into slot k % 4 of rotating buffers whose words hold a sentinel (all bits
+// set) until written; consumers poll exactly the words they need until none is a sentinel.  A
+// workgroup that has collected all (gamma, delta) records of generation k knows that everybody
+// has finished reading generation k - 1 and re-arms its own words of that slot, which will take
+// generation k + 3.  Before re-arming it waits for its earlier stores to be acknowledged (they
+// are a whole iteration old by then), so the re-arming of iteration k - 1 has landed before
+// anything of generation k + 1 is stored: whoever has seen a word of this workgroup's generation
+// k + 2 cannot find stale words in the slot of generation k + 3.  Everything another workgroup
+// reads within the launch moves through agent-scope relaxed loads and stores, which go past the
+// caches that are not coherent between the dies: no read-modify-write atomics, no cache
+// write-back or invalidation, and the matrix stays in registers (or L2).  Workgroup-internal
+// barriers order LDS traffic only and never wait for those stores.
 //
 // The grid must be co-resident (cooperative launch).  A poll that exceeds timeout_ticks clears
-// the abort word, which every polling thread checks, so the grid always drains.
+// the abort word, which every polling wavefront checks, so the grid always drains.
 constexpr int kFusedThreads = 512;
 constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr int kVecRec = 18;                       // r[6] w[6] s[6] of one camera and generation
 constexpr unsigned long long kSentinel = ~0ull;
+constexpr int kSlots = 4;                         // rotating generation slots
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
+// outstanding global stores to be acknowledged.
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 
 __device__ __forceinline__ double ld_shared(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -254,6 +266,9 @@ __device__ __forceinline__ unsigned long long ld_word(const unsigned long long* 
 __device__ __forceinline__ void st_word(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ bool is_sentinel(double v) {
+    return (unsigned long long)__double_as_longlong(v) == kSentinel;
+}
 
 // y += S x for one row-major 6x6 block.
 __device__ __forceinline__ void block_times(const double* __restrict__ S, const double (&x)[6], double (&y)[6]) {
@@ -265,214 +280,363 @@ __device__ __forceinline__ void block_times(const double* __restrict__ S, const 
     }
 }
 
-// Sum of the per-lane 6-vectors over the wavefront; lane k < 6 receives component k.
-__device__ __forceinline__ double row_total(const double (&y)[6], int lane) {
-    double q = 0.0;
-#pragma unroll
+// The same with one row of the block in flight at a time.
+__device__ __forceinline__ void block_times_rolled(const double* __restrict__ S, const double (&x)[6], double (&y)[6]) {
+    const double2* sp = reinterpret_cast<const double2*>(S);
+#pragma unroll 1
     for (int i = 0; i < 6; ++i) {
-        const double t = wave_sum(y[i]);
-        if (lane == i) q = t;
+        const double2 s0 = sp[3 * i], s1 = sp[3 * i + 1], s2 = sp[3 * i + 2];
+        const double t = s0.x * x[0] + s0.y * x[1] + s1.x * x[2] + s1.y * x[3] + s2.x * x[4] + s2.y * x[5];
+        y[0] = i == 0 ? y[0] + t : y[0]; y[1] = i == 1 ? y[1] + t : y[1]; y[2] = i == 2 ? y[2] + t : y[2];
+        y[3] = i == 3 ? y[3] + t : y[3]; y[4] = i == 4 ? y[4] + t : y[4]; y[5] = i == 5 ? y[5] + t : y[5];
     }
+}
+
+// Sum of the per-lane 6-vectors over the wavefront through the wavefront's LDS tile (at least
+// 64 x 6 + 48 doubles); lane k < 6 receives component k.  Two levels in fixed order: 48 lanes
+// (component k = lane % 6, part = lane / 6) add 8 rows each, then lane k adds the 8 parts.
+__device__ __forceinline__ double row_total(const double (&y)[6], int lane, double* tile) {
+    __builtin_amdgcn_wave_barrier();
+    double2* row = reinterpret_cast<double2*>(tile + 6 * lane);
+    row[0] = make_double2(y[0], y[1]);
+    row[1] = make_double2(y[2], y[3]);
+    row[2] = make_double2(y[4], y[5]);
+    __builtin_amdgcn_wave_barrier();
+    const int k = lane % 6, part = lane / 6;
+    double q = 0.0;
+    if (part < 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) q += tile[6 * (8 * part + r) + k];
+        tile[64 * 6 + lane] = q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) {
+        q = 0.0;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) q += tile[64 * 6 + 6 * p8 + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
     return q;
 }
 
-struct Totals { double gam, del; bool ok; };
+// Wave-level polling.  The records of up to 64 gathered columns are fetched cooperatively:
+// lane l of step t loads word e = 64 t + l of the concatenation of the records (column e / 18,
+// word e % 18), so that one instruction touches a handful of cache lines instead of 64, and
+// stores it into the wavefront's LDS tile; the poll repeats until no fetched word is a sentinel.
+constexpr int kGatherSteps = (64 * kVecRec + 63) / 64;       // 18 steps cover 64 records
 
-// Publish this workgroup's (g, dl) in `slot`, collect everybody's, return the totals.
-__device__ __forceinline__ Totals exchange(const FusedPcg& a, int slot, double g, double dl, long long deadline,
-                                           double* red, int* fail_lds) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, G = gridDim.x;
-    unsigned long long* rec = reinterpret_cast<unsigned long long*>(a.dots);
-    unsigned long long* abort_word = rec + 6 * (size_t)G;
-    g = wave_sum(g);
-    dl = wave_sum(dl);
-    if (lane == 0) { red[w] = g; red[kFusedWaves + w] = dl; }
-    if (tid == 0) *fail_lds = 0;
-    __builtin_amdgcn_s_waitcnt(0);          // this wavefront's vector stores are acknowledged
-    __syncthreads();
-    if (tid == 0) {
-        double sg = 0.0, sd = 0.0;
-        for (int i = 0; i < kFusedWaves; ++i) { sg += red[i]; sd += red[kFusedWaves + i]; }
-        unsigned long long* mine = rec + 2 * ((size_t)slot * G + blockIdx.x);
-        st_word(mine, (unsigned long long)__double_as_longlong(sg));
-        st_word(mine + 1, (unsigned long long)__double_as_longlong(sd));
+struct Poller {
+    unsigned long long* abort_word;
+    long long deadline;
+    __device__ __forceinline__ bool expired(int spins) const {
+        if ((spins & 15) != 0) return false;
+        if (ld_word(abort_word) != kSentinel) return true;
+        if ((long long)wall_clock64() > deadline) { st_word(abort_word, 0ull); return true; }
+        return false;
     }
-    double vg = 0.0, vd = 0.0;
-    int failed = 0;
-    for (int i = tid; i < G; i += kFusedThreads) {
-        const unsigned long long* theirs = rec + 2 * ((size_t)slot * G + i);
-        unsigned long long ug, ud;
+    // off[t] = word offset (column * 18 + word) of this lane's step t, negative when beyond the
+    // last record.  Returns false (wave-uniform) on abort or timeout.
+    __device__ __forceinline__ bool records(const double* gen, const int (&off)[kGatherSteps], double* tile, int lane) const {
+        constexpr int kHalf = kGatherSteps / 2;
         for (int spins = 1;; ++spins) {
-            ug = ld_word(theirs);
-            ud = ld_word(theirs + 1);
-            if (ug != kSentinel && ud != kSentinel) break;
-            if ((spins & 31) == 0) {
-                if (ld_word(abort_word) != kSentinel) { failed = 1; break; }
-                if ((long long)wall_clock64() > deadline) { st_word(abort_word, 0ull); failed = 1; break; }
-            }
-        }
-        if (failed) break;
-        vg += __longlong_as_double((long long)ug);
-        vd += __longlong_as_double((long long)ud);
-    }
-    vg = wave_sum(vg);
-    vd = wave_sum(vd);
-    if (lane == 0) { red[2 * kFusedWaves + w] = vg; red[3 * kFusedWaves + w] = vd; }
-    if (failed) *fail_lds = 1;
-    __syncthreads();
-    Totals t;
-    t.gam = 0.0;
-    t.del = 0.0;
+            bool ok = true;
 #pragma unroll
-    for (int i = 0; i < kFusedWaves; ++i) { t.gam += red[2 * kFusedWaves + i]; t.del += red[3 * kFusedWaves + i]; }
-    t.ok = *fail_lds == 0;
-    __syncthreads();
-    if (tid == 0) {
-        // re-arm the slot of the exchange after the next one: it was last read one exchange ago,
-        // which everybody has completed; the store is acknowledged (s_waitcnt at the entry of
-        // the next exchange) before this workgroup publishes again
-        unsigned long long* arm = rec + 2 * ((size_t)((slot + 2) % 3) * G + blockIdx.x);
-        st_word(arm, kSentinel);
-        st_word(arm + 1, kSentinel);
+            for (int h = 0; h < 2; ++h) {
+                double val[kHalf];
+#pragma unroll
+                for (int t = 0; t < kHalf; ++t)
+                    if (off[kHalf * h + t] >= 0) val[t] = ld_shared(gen + off[kHalf * h + t]);
+#pragma unroll
+                for (int t = 0; t < kHalf; ++t)
+                    if (off[kHalf * h + t] >= 0) {
+                        ok = ok && !is_sentinel(val[t]);
+                        tile[64 * (kHalf * h + t) + lane] = val[t];
+                    }
+            }
+            if (__all(ok)) return true;
+            if (expired(spins)) return false;
+        }
     }
-    return t;
+    // The same for the blocks [b0, b0 + nb) of any row, offsets formed on the fly, three steps in
+    // flight at a time (keeps the register footprint of this rarely hot path small).
+    __device__ __forceinline__ bool records_of(const double* gen, const int* __restrict__ bsr_col, int b0, int nb,
+                                               double* tile, int lane) const {
+        const int words = nb * kVecRec;
+        for (int spins = 1;; ++spins) {
+            bool ok = true;
+#pragma unroll 1
+            for (int e0 = 0; e0 < words; e0 += 3 * 64) {
+                double val[3];
+                int e[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    e[t] = e0 + 64 * t + lane;
+                    if (e[t] < words) {
+                        const int blk = e[t] / kVecRec;
+                        val[t] = ld_shared(gen + (size_t)bsr_col[b0 + blk] * kVecRec + (e[t] - kVecRec * blk));
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (e[t] < words) {
+                        ok = ok && !is_sentinel(val[t]);
+                        tile[e[t]] = val[t];
+                    }
+            }
+            if (__all(ok)) return true;
+            if (expired(spins)) return false;
+        }
+    }
+};
+
+// Word offsets of one lane for the blocks [b0, b0 + nb) of a row.
+__device__ __forceinline__ void gather_offsets(const int* __restrict__ bsr_col, int b0, int nb, int lane, int (&off)[kGatherSteps]) {
+#pragma unroll
+    for (int t = 0; t < kGatherSteps; ++t) {
+        const int e = 64 * t + lane, blk = e / kVecRec, j = e - kVecRec * blk;
+        off[t] = blk < nb ? bsr_col[b0 + blk] * kVecRec + j : -1;
+    }
 }
 
 __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
-    __shared__ double red[4 * kFusedWaves];
+    __shared__ double red[2 * kFusedWaves];
+    __shared__ double2 dotbuf[kFusedWaves];
+    __shared__ __attribute__((aligned(16))) double tiles[kFusedWaves][64 * kVecRec];
     __shared__ int fail_lds;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int G = gridDim.x, W = G * kFusedWaves, gw = blockIdx.x * kFusedWaves + w;
-    const long long deadline = (long long)wall_clock64() + a.timeout_ticks;
+    const long long t_start = (long long)wall_clock64();
+    unsigned long long* drec = reinterpret_cast<unsigned long long*>(a.dots);
+    double* tile = tiles[w];
+    Poller poll;
+    poll.abort_word = drec + 2 * kSlots * (size_t)G;
+    poll.deadline = t_start + a.timeout_ticks;
+    const size_t gen_stride = (size_t)a.n_cam * kVecRec;
+    if (tid == 0) fail_lds = 0;
 
-    // the first row of this wavefront stays in registers for the whole solve: block range,
-    // this lane's column and its 6x6 block
-    int c_b = 0, c_b1 = 0;
-    size_t c_col = 0;
+    // the first (up to) 64 blocks of the first row of this wavefront stay in registers for the
+    // whole solve: this lane's 6x6 block and its word offsets of the cooperative gather
+    int c_b0 = 0, c_nb = 0, c_rest = 0;
+    int c_off[kGatherSteps];
     double c_S[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) c_S[i] = 0.0;
+#pragma unroll
+    for (int t = 0; t < kGatherSteps; ++t) c_off[t] = -1;
     if (gw < a.n_cam) {
-        c_b = a.bsr_ptr[gw] + lane;
-        c_b1 = a.bsr_ptr[gw + 1];
-        if (c_b < c_b1) {
-            c_col = 6 * (size_t)a.bsr_col[c_b];
-            const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)c_b);
+        c_b0 = a.bsr_ptr[gw];
+        c_rest = a.bsr_ptr[gw + 1];
+        c_nb = c_rest - c_b0 < 64 ? c_rest - c_b0 : 64;
+        gather_offsets(a.bsr_col, c_b0, c_nb, lane, c_off);
+        if (lane < c_nb) {
+            const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)(c_b0 + lane));
 #pragma unroll
             for (int i = 0; i < 18; ++i) { const double2 v = sp[i]; c_S[2 * i] = v.x; c_S[2 * i + 1] = v.y; }
         }
     }
+    // own vectors of the first row (lanes < 6): r, w of the current generation, s of the previous, p, xhat
+    double o_r = 0.0, o_w = 0.0, o_s = 0.0, o_p = 0.0, o_x = 0.0;
 
-    // iteration "-1": r0 = bhat, w0 = Shat r0, p = s = xhat = 0
-    double g = 0.0, dl = 0.0;
-    for (int row = gw; row < a.n_cam; row += W) {
-        double y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        const int b1 = a.bsr_ptr[row + 1];
-        for (int b = a.bsr_ptr[row] + lane; b < b1; b += 64) {
-            const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b]);
-            const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
-            const double rc[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
-            block_times(a.Shat + 36 * (size_t)b, rc, y);
+    // workgroup partial of (gamma, delta) -> record of generation `gen`
+    auto publish = [&](double g, double dl, int gen) {
+        // only lanes < 6 hold anything: lane 0 adds the six pairs through the LDS tile
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) reinterpret_cast<double2*>(tile)[lane] = make_double2(g, dl);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double sg = 0.0, sd = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const double2 v = reinterpret_cast<const double2*>(tile)[i]; sg += v.x; sd += v.y; }
+            red[w] = sg; red[kFusedWaves + w] = sd;
         }
-        const double q = row_total(y, lane);
-        if (lane < 6) {
-            const size_t o = 6 * (size_t)row + lane;
-            const double rk = a.bhat[o];
-            st_shared(a.r[0] + o, rk); st_shared(a.w[0] + o, q); st_shared(a.s[1] + o, 0.0);
-            a.p[o] = 0.0; a.xh[o] = 0.0;
-            g += rk * rk;
-            dl += q * rk;
+        block_barrier();
+        if (tid == 0) {
+            double sg = 0.0, sd = 0.0;
+            for (int i = 0; i < kFusedWaves; ++i) { sg += red[i]; sd += red[kFusedWaves + i]; }
+            unsigned long long* mine = drec + 2 * ((size_t)(gen % kSlots) * G + blockIdx.x);
+            st_word(mine, (unsigned long long)__double_as_longlong(sg));
+            st_word(mine + 1, (unsigned long long)__double_as_longlong(sd));
         }
+    };
+
+    // generation 0: r0 = bhat, w0 = Shat r0, s = p = xhat = 0
+    {
+        double g = 0.0, dl = 0.0;
+        for (int row = gw; row < a.n_cam; row += W) {
+            double y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int b1 = a.bsr_ptr[row + 1];
+            for (int b = a.bsr_ptr[row] + lane; b < b1; b += 64) {
+                const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b]);
+                const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
+                const double rc[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+                block_times(a.Shat + 36 * (size_t)b, rc, y);
+            }
+            const double q = row_total(y, lane, tile);
+            if (lane < 6) {
+                const double rk = a.bhat[6 * (size_t)row + lane];
+                double* rec = a.vec + (size_t)row * kVecRec;
+                st_shared(rec + lane, rk); st_shared(rec + 6 + lane, q); st_shared(rec + 12 + lane, 0.0);
+                if (row == gw) { o_r = rk; o_w = q; }
+                else { a.p[6 * (size_t)row + lane] = 0.0; a.xh[6 * (size_t)row + lane] = 0.0; }
+                g += rk * rk;
+                dl += q * rk;
+            }
+        }
+        publish(g, dl, 0);
     }
-    Totals tot = exchange(a, 0, g, dl, deadline, red, &fail_lds);
 
-    double gam = tot.gam, gam0 = tot.gam, gam_prev = 0.0, alpha_prev = 0.0;
-    int it = 0, flag = tot.ok ? 0 : 2;
-    while (flag == 0) {
-        const int par = it & 1;
-        gam = tot.gam;
+    double gam = 0.0, gam0 = 0.0, gam_prev = 0.0, den_prev = 0.0;
+    int it = 0, flag = 0;
+    for (;;) {
+        const int slot = it % kSlots;
+        const double* vcur = a.vec + (size_t)slot * gen_stride;
+        // generation `it`: the records the first row gathers and every workgroup's (gamma, delta)
+        bool okw = poll.records(vcur, c_off, tile, lane);
+        double sum_g = 0.0, sum_d = 0.0;
+        if (okw) {
+            // (polled after the records: the (gamma, delta) records are published last, and a
+            // joint poll would keep re-fetching the vector records while waiting for them)
+            const bool reader = tid < G;
+            const unsigned long long* theirs = drec + 2 * ((size_t)slot * G + (reader ? tid : 0));
+            for (int spins = 1;; ++spins) {
+                bool ok = true;
+                if (reader) {
+                    const unsigned long long ug = ld_word(theirs), ud = ld_word(theirs + 1);
+                    ok = ug != kSentinel && ud != kSentinel;
+                    sum_g = __longlong_as_double((long long)ug);
+                    sum_d = __longlong_as_double((long long)ud);
+                }
+                if (__all(ok)) break;
+                if (poll.expired(spins)) { okw = false; break; }
+            }
+            if (!reader || !okw) { sum_g = 0.0; sum_d = 0.0; }
+        }
+        sum_g = wave_sum(sum_g);
+        sum_d = wave_sum(sum_d);
+        if (lane == 0) dotbuf[w] = make_double2(sum_g, sum_d);
+        if (!okw && lane == 0) fail_lds = 1;
+        block_barrier();
+        if (fail_lds) { flag = 2; break; }
+        double del = 0.0;
+        gam = 0.0;
+#pragma unroll
+        for (int i = 0; i < kFusedWaves; ++i) { const double2 v = dotbuf[i]; gam += v.x; del += v.y; }
         if (it == 0) {
+            gam0 = gam;
             if (!(gam > 0.0)) break;                        // zero (or NaN) right-hand side
         } else if (!(gam > a.tol2 * gam0) || it >= a.max_iter) {
             break;
         }
+        // 1 / alpha = delta / gamma - beta / alpha_prev, i.e. den = delta - beta^2 den_prev
         const double beta = it ? gam / gam_prev : 0.0;
-        const double den = it ? tot.del - beta * gam / alpha_prev : tot.del;
+        const double den = del - beta * beta * den_prev;
         if (!(den > 0.0)) { flag = 1; break; }               // breakdown: caller falls back
         const double alpha = gam / den;
         gam_prev = gam;
-        alpha_prev = alpha;
-        const double* ro = a.r[par];
-        const double* wo = a.w[par];
-        const double* so = a.s[par ^ 1];
-        g = 0.0;
-        dl = 0.0;
-        for (int row = gw; row < a.n_cam; row += W) {
+        den_prev = den;
+
+        __builtin_amdgcn_s_waitcnt(0);          // see the re-arming below
+        double* vnext = a.vec + (size_t)((it + 1) % kSlots) * gen_stride;
+        double g = 0.0, dl = 0.0;
+        for (int row = gw; row < a.n_cam && okw; row += W) {
             const bool first = row == gw;
-            const int b1 = first ? c_b1 : a.bsr_ptr[row + 1];
-            int b = first ? c_b : a.bsr_ptr[row] + lane;
-            // the owner's own values travel with the gather: one round trip for both
-            const size_t o = 6 * (size_t)row + (lane < 6 ? lane : 0);
-            const double rk = ld_shared(ro + o), wk = ld_shared(wo + o), sk = ld_shared(so + o);
-            const double pk = a.p[o], xk = a.xh[o];
             double y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (b < b1) {
-                const size_t col = first ? c_col : 6 * (size_t)a.bsr_col[b];
-                double rc[6];
+            double rk = o_r, wk = o_w, sk = o_s, pk = o_p, xk = o_x;
+            int b0 = c_b0 + c_nb;                        // blocks of the row not yet done
+            const int b1 = first ? c_rest : a.bsr_ptr[row + 1];
+            if (first) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane < c_nb) {
+                    const double* u = tile + kVecRec * lane;
+                    double rc[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    rc[j] = fma(-alpha, fma(beta, ld_shared(so + col + j), ld_shared(wo + col + j)), ld_shared(ro + col + j));
-                if (first) {
+                    for (int j = 0; j < 6; ++j) rc[j] = fma(-alpha, fma(beta, u[12 + j], u[6 + j]), u[j]);
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
                         y[i] = c_S[6 * i] * rc[0] + c_S[6 * i + 1] * rc[1] + c_S[6 * i + 2] * rc[2] +
                                c_S[6 * i + 3] * rc[3] + c_S[6 * i + 4] * rc[4] + c_S[6 * i + 5] * rc[5];
-                } else {
-                    block_times(a.Shat + 36 * (size_t)b, rc, y);
                 }
-                for (b += 64; b < b1; b += 64) {
-                    const size_t col2 = 6 * (size_t)a.bsr_col[b];
+            } else {
+                b0 = a.bsr_ptr[row];
+                if (lane < 6) { pk = a.p[6 * (size_t)row + lane]; xk = a.xh[6 * (size_t)row + lane]; }
+            }
+            const int dpos = first ? -1 : a.bsr_diag[row];
+            for (; b0 < b1 && okw; b0 += 64) {
+                const int nb = b1 - b0 < 64 ? b1 - b0 : 64;
+                __builtin_amdgcn_wave_barrier();
+                okw = poll.records_of(vcur, a.bsr_col, b0, nb, tile, lane);
+                __builtin_amdgcn_wave_barrier();
+                if (!okw) break;
+                if (lane < nb) {
+                    const double* u = tile + kVecRec * lane;
+                    double rc[6];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j)
-                        rc[j] = fma(-alpha, fma(beta, ld_shared(so + col2 + j), ld_shared(wo + col2 + j)), ld_shared(ro + col2 + j));
-                    block_times(a.Shat + 36 * (size_t)b, rc, y);
+                    for (int j = 0; j < 6; ++j) rc[j] = fma(-alpha, fma(beta, u[12 + j], u[6 + j]), u[j]);
+                    block_times_rolled(a.Shat + 36 * (size_t)(b0 + lane), rc, y);
+                }
+                if (dpos >= b0 && dpos < b0 + nb && lane < 6) {     // the owner's own record came along
+                    const double* u = tile + kVecRec * (dpos - b0);
+                    rk = u[lane]; wk = u[6 + lane]; sk = u[12 + lane];
                 }
             }
-            const double q = row_total(y, lane);
+            if (!okw) break;
+            const double q = row_total(y, lane, tile);
             if (lane < 6) {
                 const double sn = fma(beta, sk, wk);
                 const double pn = fma(beta, pk, rk);
                 const double rn = fma(-alpha, sn, rk);
-                a.xh[o] = fma(alpha, pn, xk);
-                a.p[o] = pn;
-                st_shared(a.s[par] + o, sn);
-                st_shared(a.r[par ^ 1] + o, rn);
-                st_shared(a.w[par ^ 1] + o, q);
+                const double xn = fma(alpha, pn, xk);
+                double* rec = vnext + (size_t)row * kVecRec;
+                st_shared(rec + lane, rn); st_shared(rec + 6 + lane, q); st_shared(rec + 12 + lane, sn);
+                if (first) { o_r = rn; o_w = q; o_s = sn; o_p = pn; o_x = xn; }
+                else { a.p[6 * (size_t)row + lane] = pn; a.xh[6 * (size_t)row + lane] = xn; }
                 g += rn * rn;
                 dl += q * rn;
             }
         }
+        if (!okw && lane == 0) fail_lds = 1;
         ++it;
-        tot = exchange(a, it % 3, g, dl, deadline, red, &fail_lds);
-        if (!tot.ok) flag = 2;
+        publish(g, dl, it);
+        // Everybody has left generation it - 1 (all records of generation `it` were collected
+        // above): re-arm this workgroup's words of its slot, which will take generation it + 3.
+        // These stores trail the data stores so that nothing in this iteration waits for their
+        // acknowledgement; the wait further up (before the data stores of the next iteration,
+        // when every load of that iteration's poll has already come back) makes sure they have
+        // landed before anything of generation it + 2 is stored.
+        {
+            double* arm = a.vec + (size_t)((it + kSlots - 2) % kSlots) * gen_stride;
+            if (lane < 6)
+                for (int row = gw; row < a.n_cam; row += W) {
+                    unsigned long long* rec = reinterpret_cast<unsigned long long*>(arm + (size_t)row * kVecRec);
+                    st_word(rec + lane, kSentinel); st_word(rec + 6 + lane, kSentinel); st_word(rec + 12 + lane, kSentinel);
+                }
+            if (tid == 0) {
+                unsigned long long* rec = drec + 2 * ((size_t)((it + kSlots - 2) % kSlots) * G + blockIdx.x);
+                st_word(rec, kSentinel);
+                st_word(rec + 1, kSentinel);
+            }
+        }
+
+        if (fail_lds) { flag = 2; break; }      // read after the barrier inside publish
     }
     // x = F' xhat for the rows this wavefront owns
     if (flag != 2) {
         for (int row = gw; row < a.n_cam; row += W) {
-            const double xk = lane < 6 ? a.xh[6 * (size_t)row + lane] : 0.0;
-            double v = 0.0;
+            double xk = 0.0;
+            if (lane < 6) xk = row == gw ? o_x : a.xh[6 * (size_t)row + lane];
+            double val = 0.0;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const double xj = __shfl(xk, j, 64);
-                if (lane < 6) v += a.F[36 * (size_t)row + 6 * j + lane] * xj;
+                if (lane < 6) val += a.F[36 * (size_t)row + 6 * j + lane] * xj;
             }
-            if (lane < 6) a.x[6 * (size_t)row + lane] = v;
+            if (lane < 6) a.x[6 * (size_t)row + lane] = val;
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
         PcgState st;
         st.rz = gam; st.rz0 = gam0; st.tol2 = a.tol2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
-        st.ticks = (long long)wall_clock64() - (deadline - a.timeout_ticks);
+        st.ticks = (long long)wall_clock64() - t_start;
         *a.out = st;
     }
 }
@@ -481,15 +645,19 @@ int pcg_fused_max_blocks(int device) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_fused, kFusedThreads, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    return per_cu > 0 ? cus : 0;          // one workgroup per compute unit keeps the exchange cheap
+    // one workgroup per compute unit; every workgroup's record is polled by one thread
+    return per_cu > 0 ? (cus < kFusedThreads ? cus : kFusedThreads) : 0;
 }
 
 int pcg_fused_rows_per_block() { return kFusedWaves; }
-size_t pcg_fused_record_words(int blocks) { return 6 * (size_t)blocks + 1; }
+size_t pcg_fused_record_words(int blocks) { return 2 * kSlots * (size_t)blocks + 1; }
+size_t pcg_fused_vector_words(int n_cam) { return kSlots * (size_t)n_cam * kVecRec; }
 
-// Arms every record slot and the abort word (all bits set), then launches the solve.
+// Arms every record (all bits set) and the abort word, then launches the solve.
 hipError_t launch_pcg_fused(const FusedPcg& f, int blocks, hipStream_t st) {
     hipError_t e = hipMemsetAsync(f.dots, 0xFF, pcg_fused_record_words(blocks) * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(f.vec, 0xFF, pcg_fused_vector_words(f.n_cam) * sizeof(double), st);
     if (e != hipSuccess) return e;
     FusedPcg arg = f;
     void* params[] = {&arg};

@@ -44,6 +44,7 @@ class Options(C.Structure):
         ("pcg_max_iter", C.c_int32), ("pcg_batch", C.c_int32), ("linear_solver", C.c_int32), ("schur_mode", C.c_int32),
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
+        ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32),
     ]
 
 
@@ -66,6 +67,7 @@ class Stats(C.Structure):
         ("ms_pairs", C.c_double), ("n_pairs", C.c_int64),
         ("ms_bsr", C.c_double), ("n_bsr", C.c_int64),
         ("schur_pairs", C.c_int64), ("schur_blocks", C.c_int64), ("schur_chunks", C.c_int64),
+        ("pcg_single_launch", C.c_int64), ("pcg_single_fallbacks", C.c_int64),
     ]
 
     def as_dict(self):

@@ -16,7 +16,8 @@ from structure_from_motion_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
-           "pcg-explicit": dict(linear_solver=1, schur_mode=2),
+           "pcg-explicit": dict(linear_solver=1, schur_mode=2, pcg_mode=2),
+           "pcg-explicit-stepwise": dict(linear_solver=1, schur_mode=2, pcg_mode=1),
            "dense": dict(linear_solver=2)}
 
 

@@ -16,10 +16,12 @@ from structure_from_motion_amd.engine import Engine, EngineError
 
 pytestmark = pytest.mark.gpu
 
-# (linear_solver, schur_mode): PCG on the implicit operator, PCG on the explicit block-sparse
-# matrix, dense MFMA Cholesky on the explicit matrix
+# (linear_solver, schur_mode, pcg_mode): PCG on the implicit operator, PCG on the explicit
+# block-sparse matrix as one cooperative launch and as two launches per iteration, dense MFMA
+# Cholesky on the explicit matrix
 SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
-           "pcg-explicit": dict(linear_solver=1, schur_mode=2),
+           "pcg-explicit": dict(linear_solver=1, schur_mode=2, pcg_mode=2),
+           "pcg-explicit-stepwise": dict(linear_solver=1, schur_mode=2, pcg_mode=1),
            "dense": dict(linear_solver=2)}
 
 
@@ -169,6 +171,10 @@ def test_solve_with_reference_tolerances_not_worse_than_scipy(name, solver):
     assert st.status in (1, 2, 3, 4)
     assert st.linear_solver == (2 if solver == "dense" else 1)
     assert st.schur_mode == (1 if solver == "pcg-implicit" else 2)
+    if solver == "pcg-explicit":            # every linear solve went through the single launch
+        assert st.pcg_single_launch == st.iterations and st.pcg_single_fallbacks == 0
+    else:
+        assert st.pcg_single_launch == 0
     assert abs(st.initial_cost - float(g["ref_initial_cost"])) <= 1e-10 * float(g["ref_initial_cost"])
     assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)
     # the returned 12-number poses reproduce the reported cost under the oracle's fun()
@@ -185,6 +191,42 @@ def test_converged_cost_matches_scipy(name, solver):
                      **SOLVERS[solver]) as eng:
         st = eng.solve()
     assert abs(st.final_cost - float(g["tight_cost"])) <= 1e-6 * float(g["tight_cost"])
+
+
+@pytest.mark.parametrize("blocks", [0, 1, 3])
+def test_single_launch_pcg_with_long_rows_and_several_rows_per_wavefront(blocks):
+    # 120 cameras that each share points with ~100 others: block rows longer than the 64 blocks
+    # a wavefront keeps in registers; 1 or 3 workgroups: 5 to 15 rows per wavefront
+    g = syn.make_problem(120, 3000, 24000, seed=3, window=60)
+    lam = 1e-4
+    with make_engine(g, pcg_rtol=1e-12, pcg_max_iter=2000, linear_solver=1, schur_mode=2, pcg_mode=1) as eng:
+        eng.linearize(lam)
+        dc_ref, dp_ref, it_ref = eng.solve_step()
+        cost_ref = eng.solve().final_cost
+    with make_engine(g, pcg_rtol=1e-12, pcg_max_iter=2000, linear_solver=1, schur_mode=2, pcg_mode=2,
+                     pcg_blocks=blocks) as eng:
+        eng.linearize(lam)
+        dc, dp, it = eng.solve_step()
+        st = eng.solve()
+    assert rel_err(dc, dc_ref) <= 1e-8 and rel_err(dp, dp_ref) <= 1e-8
+    assert abs(it - it_ref) <= max(3, it_ref // 10)
+    assert st.pcg_single_launch == st.iterations and st.pcg_single_fallbacks == 0
+    assert abs(st.final_cost - cost_ref) <= 1e-9 * cost_ref
+
+
+def test_single_launch_pcg_zero_right_hand_side_and_iteration_cap():
+    g = load_golden("shuffled_9_200_700")
+    with make_engine(g, pcg_max_iter=1, pcg_rtol=1e-12, linear_solver=1, schur_mode=2, pcg_mode=2) as eng:
+        eng.linearize(1e-3)
+        _, _, it = eng.solve_step()
+        assert it == 1                                    # the cap is honoured
+    # at the exact optimum of a noise-free problem the gradient, hence the right-hand side, is 0
+    p = syn.make_problem(6, 80, 300, seed=2, noise_px=0.0)
+    p["camera_params"], p["points_3d"] = p["true_camera_params"], p["true_points_3d"]
+    with make_engine(p, linear_solver=1, schur_mode=2, pcg_mode=2) as eng:
+        eng.linearize(1e-3)
+        dc, dp, it = eng.solve_step()
+    assert np.abs(dc).max() < 1e-6 and np.abs(dp).max() < 1e-6
 
 
 def test_dense_cholesky_is_the_fallback_when_pcg_runs_out_of_iterations():
