@@ -32,7 +32,7 @@ def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks):
              observation's seed record once (32), every point's inverse block once (48), one
              36-double partial row per chunk (288)
     bsr      k_pcg_spmv_bsr: the block-CSR matrix once (288 + 4 per block, n_pairs here = blocks),
-             three vectors read and two written per camera (240)
+             three vectors read and two written per camera (240); k_pcg_fused: see main()
     spmv_pm  implicit matvec, point-major half: camera index + seed record per observation (36),
              point index (4), inverse block (48) and product written (32) per point, iterate +
              rotation per camera (120)
@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--linear-solver", type=int, default=0, help="0 auto, 1 PCG, 2 dense Cholesky")
     ap.add_argument("--schur-mode", type=int, default=0, help="0 auto, 1 implicit, 2 explicit")
+    ap.add_argument("--pcg-mode", type=int, default=0, help="0 auto, 1 two launches per iteration, 2 single launch")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +98,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
-    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode)
+    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode)
     eng = Engine(device=local_rank, rank=rank, nranks=world, **solver_opts)
     t0 = time.time()
     eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
@@ -148,7 +149,12 @@ def main():
         cam_counts = np.bincount(p["camera_indices"], minlength=p["n_cameras"])
         n_chunks = int(np.sum((cam_counts + chunk - 1) // chunk))
         ab = algorithmic_bytes(n_obs, p["n_points"], p["n_cameras"], n_chunks, ps.schur_pairs, ps.schur_chunks)
-        ab["bsr"] = 292 * ps.schur_blocks + 240 * p["n_cameras"]
+        if ps.pcg_single_launch:
+            # single-launch PCG: the matrix lives in registers; one iteration moves the 18-word
+            # record of every gathered column and of every row written (through memory, past L2)
+            ab["bsr"] = 144 * ps.schur_blocks + 144 * p["n_cameras"]
+        else:
+            ab["bsr"] = 292 * ps.schur_blocks + 240 * p["n_cameras"]
         families = {}
         for fam in ("linearize", "damp", "schur", "pairs", "bsr", "spmv_pm", "spmv_cm", "pcg_vec", "back", "cost", "dense"):
             n = getattr(ps, "n_" + fam)
@@ -165,7 +171,8 @@ def main():
             avg_s = families[f]["avg_us"] * 1e-6
             return ab[f] / avg_s / 1e9 if avg_s > 0 else 0.0
 
-        kernel_name = {"pairs": "k_schur_pairs", "bsr": "k_pcg_spmv_bsr", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm"}
+        kernel_name = {"pairs": "k_schur_pairs", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm",
+                       "bsr": "k_pcg_fused (per PCG iteration)" if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
         # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
         traffic = None
@@ -202,7 +209,8 @@ def main():
                                     "ftol=1e-4 xtol=1e-12 gtol=1e-8"),
                        "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU",
                        "linear_solver": {1: "pcg", 2: "dense-cholesky"}[last.linear_solver],
-                       "schur_mode": {1: "implicit", 2: "explicit"}[last.schur_mode]},
+                       "schur_mode": {1: "implicit", 2: "explicit"}[last.schur_mode],
+                       "pcg": "single cooperative launch" if last.pcg_single_launch else "launch per iteration"},
             "lm_iters_per_sec": iters / elapsed,
             "lm_iterations_per_solve": iters / args.steps,
             "pcg_iterations_per_solve": sum(s.pcg_iterations for s in stats) / args.steps,
