@@ -388,7 +388,16 @@ void phase_linearize(H* h) {
     launch_lin_pm(h->dev, h->stream);
     launch_lin_cm(h->dev, h->stream);
     launch_chunk_reduce(h->dev, 27, h->UG.p, h->stream);
-    allreduce(h, h->UG.p, (size_t)h->n_cam * 27);
+    if (h->has_comm()) {
+        // one collective for the camera blocks and the gradient maximum over the points: the
+        // maximum travels as one slot per rank behind the blocks (a sum all-reduce of slots of
+        // which only one rank fills each)
+        const int nr = h->opt.nranks;
+        double* slots = h->UG.p + (size_t)h->n_cam * 27;
+        HIP_TRY(hipMemsetAsync(slots, 0, nr * sizeof(double), h->stream));
+        HIP_TRY(hipMemcpyAsync(slots + h->opt.rank, h->scalars.p + SLOT_GMAX_PT, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        allreduce(h, h->UG.p, (size_t)h->n_cam * 27 + nr);
+    }
     launch_gmax_cam(h->dev, h->stream);
     h->linearized = false;
 }
@@ -397,6 +406,7 @@ void phase_linearize(H* h) {
 // mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
     if (h->explicit_schur) {
+        double* bpart = h->Bsum.p + (size_t)h->n_ublk * 36;      // sum W Vinv g_p, behind the blocks
         {
             Scope t(h, F_DAMP);
             launch_damp_pm(h->dev, lambda, h->stream);
@@ -404,7 +414,7 @@ void phase_damp(H* h, double lambda) {
         {
             Scope t(h, F_DAMP);
             launch_spmv_cm(h->dev, h->s0.p, nullptr, h->stream);         // sum W Vinv g_p
-            launch_chunk_reduce(h->dev, 6, h->qS.p, h->stream);
+            launch_chunk_reduce(h->dev, 6, bpart, h->stream);
         }
         {
             Scope t(h, F_SCHUR);
@@ -414,11 +424,10 @@ void phase_damp(H* h, double lambda) {
             }
             launch_block_reduce(h->dev, h->stream);
         }
-        allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
-        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36);
+        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36 + (size_t)h->n_cam * 6);
         {
             Scope t(h, F_SCHUR);
-            launch_schur_finish(h->dev, lambda, h->qS.p, h->stream);
+            launch_schur_finish(h->dev, lambda, bpart, h->stream);
             if (h->fused_pcg) launch_schur_scale(h->dev, h->fused, h->stream);
         }
     } else {
@@ -581,19 +590,17 @@ void phase_trial(H* h, double* dp_out) {
     reduce_scalars(h, SLOT_MODEL, SLOT_NONFINITE - SLOT_MODEL + 1);
 }
 
-double gather_gmax_pt(H* h, double local) {
-    // max over ranks of a non-negative scalar through a sum all-reduce of one slot per rank
-    if (!h->has_comm()) return local;
-    int nr = h->opt.nranks;
-    std::vector<double> slots(nr, 0.0);
-    slots[h->opt.rank] = local;
-    HIP_TRY(hipMemcpyAsync(h->tmp_b.p, slots.data(), nr * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    allreduce(h, h->tmp_b.p, nr);
-    HIP_TRY(hipMemcpyAsync(slots.data(), h->tmp_b.p, nr * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    double m = 0;
+// Scalars of the linearisation: the slots, and the largest |g_p| over all partitions.
+double read_lin_scalars(H* h, double* sc) {
+    std::vector<double> slots;
+    if (h->has_comm()) {
+        slots.resize(h->opt.nranks);
+        HIP_TRY(hipMemcpyAsync(slots.data(), h->UG.p + (size_t)h->n_cam * 27, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    read_scalars(h, sc);
+    double m = sc[SLOT_GMAX_PT];
     for (double v : slots) m = std::max(m, v);
-    return m;
+    return std::max(sc[SLOT_GMAX_CAM], m);
 }
 
 void print_header() {
@@ -627,9 +634,8 @@ void do_solve(H* h, sfmba_stats* out) {
     phase_linearize(h);
     st.njev = 1;
     reduce_scalars(h, SLOT_COST, 1);
-    read_scalars(h, sc);
+    double g_norm = read_lin_scalars(h, sc);
     double cost = 0.5 * sc[SLOT_COST];
-    double g_norm = std::max(sc[SLOT_GMAX_CAM], gather_gmax_pt(h, sc[SLOT_GMAX_PT]));
     st.nfev = 1;
     st.initial_cost = cost;
     if (!std::isfinite(cost)) fail(SFMBA_ERR_NONFINITE, "Residuals are not finite in the initial point.");
@@ -665,8 +671,7 @@ void do_solve(H* h, sfmba_stats* out) {
             cost = cost_new;
             phase_linearize(h);          // also the gradient norm at the new iterate
             st.njev++;
-            read_scalars(h, sc);
-            g_norm = std::max(sc[SLOT_GMAX_CAM], gather_gmax_pt(h, sc[SLOT_GMAX_PT]));
+            g_norm = read_lin_scalars(h, sc);
             if (talk) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, false);
             if (ft && xt) status = SFMBA_STATUS_FTOL_XTOL;
             else if (ft) status = SFMBA_STATUS_FTOL;
@@ -914,7 +919,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
     h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);
     h->pair_part.alloc((size_t)std::max<size_t>(pchunk_blk.size(), 1) * 36);
-    h->Bsum.alloc((size_t)n_ublk * 36);
+    h->Bsum.alloc((size_t)n_ublk * 36 + (size_t)n_cam * 6);      // + the reduced right-hand side part, one collective
     h->Sfull.alloc((size_t)nnzb * 36);
     h->Bsum.zero(st); h->Sfull.zero(st);
     HIP_TRY(hipStreamSynchronize(st));
@@ -1086,7 +1091,8 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->V.zero(st); h->gp.zero(st);      // points without observations are never written
     h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
     h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * 27);
-    h->UG.alloc((size_t)n_cam * 27); h->T.alloc((size_t)n_cam * 27);
+    h->UG.alloc((size_t)n_cam * 27 + (size_t)std::max(1, h->opt.nranks)); h->T.alloc((size_t)n_cam * 27);
+    h->UG.zero(h->stream);
     h->Minv.alloc((size_t)n_cam * 36); h->rhs.alloc((size_t)n_cam * 6);
     for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp[0], &h->pp[1], &h->pq, &h->qS}) b->alloc((size_t)n_cam * 6);
     h->nb_bsr = bsr_blocks_host((int)n_cam);
