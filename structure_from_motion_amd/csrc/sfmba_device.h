@@ -23,6 +23,14 @@ __device__ __forceinline__ Cam load_cam(const double2* __restrict__ cams, int c)
     return k;
 }
 
+// A value that is the same in every lane, moved into scalar registers.
+__device__ __forceinline__ double wave_uniform(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Normalised image coordinates of a point in a camera: x = Y0/Z, y = Y1/Z, iz = 1/Z with the
 // cv2.projectPoints guard (Z == 0 is treated as Z == 1).
 struct Seed { double x, y, iz; };

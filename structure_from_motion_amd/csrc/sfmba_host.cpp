@@ -797,7 +797,7 @@ struct KeySet {
 // its transpose land in it.
 void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, const int64_t* pt_idx,
                            const std::vector<int64_t>& pre, const std::vector<int>& pt_ptr,
-                           const std::vector<int>& pm_cam, const std::vector<int>& pm_pt) {
+                           const std::vector<int>& pm_cam, const std::vector<int>& pm2cm) {
     const int n_cam = (int)h->n_cam, np = h->n_pts, no = h->n_obs;
     int mode = h->opt.schur_mode;
     if (const char* e = getenv("SFMBA_SCHUR_MODE")) mode = atoi(e);
@@ -885,7 +885,8 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         std::vector<int> bf(bcount.begin(), bcount.end() - 1);
         for_each_pair([&](int u, int a, int b, int p) { const int k = bf[u]++; pa[k] = a; pb[k] = b; pp[k] = p; });
     }
-    (void)pm_pt;
+    // the pair kernel reads the camera-major seed arrays
+    for (int64_t k = 0; k < n_pairs; ++k) { pa[k] = pm2cm[pa[k]]; pb[k] = pm2cm[pb[k]]; }
     // pair chunks
     int pchunk = 512;
     if (const char* e = getenv("SFMBA_PAIR_CHUNK")) { int v = atoi(e); if (v >= 64) pchunk = v; }
@@ -1044,10 +1045,11 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     for (int j = 0; j < no; ++j) cam_ptr[pm_cam[j] + 1]++;
     for (int64_t c = 0; c < n_cam; ++c) cam_ptr[c + 1] += cam_ptr[c];
     std::vector<int> cfill(cam_ptr.begin(), cam_ptr.end() - 1);
-    std::vector<int> cm_pt(no);
+    std::vector<int> cm_pt(no), pm2cm(no);
     std::vector<double2> cm_uv(no);
     for (int j = 0; j < no; ++j) {
         int k = cfill[pm_cam[j]]++;
+        pm2cm[j] = k;
         cm_pt[k] = pm_pt[j];
         cm_uv[k] = pm_uv[j];
     }
@@ -1102,7 +1104,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         h->dot_off = std::max(h->nb_cam, pcg_spmv_blocks(t));       // p'q partials, then r'z partials
         h->pcg.alloc(2); h->dot_part.alloc((size_t)h->dot_off + pcg_update_blocks(t));
     }
-    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm_pt);
+    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm2cm);
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
     h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
     h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * 36));

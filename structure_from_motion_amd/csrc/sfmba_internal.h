@@ -114,7 +114,7 @@ struct Dev {
     const int* ublk_chunk_ptr;                    // [n_ublk+1] pair-chunk range of each upper block
     const int* ublk_pos; const int* ublk_pos_t;   // [n_ublk] slots of (r,c) and (c,r) in Sfull
     const int* pchunk_blk; const int* pchunk_beg; // [n_pchunks], [n_pchunks+1]
-    const int* pair_a; const int* pair_b; const int* pair_p;   // [n_pairs] pm indices of the two observations, point
+    const int* pair_a; const int* pair_b; const int* pair_p;   // [n_pairs] camera-major indices of the two observations, point
     double* pair_part;        // [n_pchunks][36]
     double* Bsum;             // [n_ublk][36] sum W_a Vinv W_b' per upper block (all ranks' sum)
     const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;   // [n_cam+1], [nnzb], [n_cam]

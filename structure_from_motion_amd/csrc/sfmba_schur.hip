@@ -5,7 +5,7 @@
 // observations (a, b) of one point with camera(a) = r and camera(b) = c, sorted by block and cut
 // into chunks; one wavefront owns one chunk, both cameras are wave-uniform, every lane forms
 //     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (6x2 . 2x2 . 2x6)
-// for its pairs from the stored seeds, sums in registers, and the wavefront reduces the 36 sums
+// for its pairs from the stored camera-major seeds, sums in registers, and the wavefront reduces the 36 sums
 // through an LDS tile into one partial row per chunk.  A per-block pass adds the chunk rows
 // in fixed order (bitwise reproducible, no atomics), a finishing pass mirrors the upper blocks
 // into a full block-CSR matrix and adds the damped U blocks on the diagonal.  The reduced system
@@ -30,21 +30,29 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
     const int k1 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q + 1]);
     const int r = __builtin_amdgcn_readfirstlane(d.ublk_r[blk]);
     const int c = __builtin_amdgcn_readfirstlane(d.ublk_c[blk]);
-    const Cam camr = load_cam(d.cams, r);
-    const Cam camc = load_cam(d.cams, c);
+    // both cameras are the same for the whole wavefront: their rotations live in scalar registers
+    double qr[9], qc[9];
+    {
+        const Cam camr = load_cam(d.cams, r);
+        const Cam camc = load_cam(d.cams, c);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { qr[i] = wave_uniform(camr.q[i]); qc[i] = wave_uniform(camc.q[i]); }
+    }
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         const int ja = d.pair_a[k], jb = d.pair_b[k], p = d.pair_p[k];
-        const double4 da = d.pm_seed[ja], db = d.pm_seed[jb];
-        Seed sa; sa.x = da.x; sa.y = da.y; sa.iz = da.z;
-        Seed sb; sb.x = db.x; sb.y = db.y; sb.iz = db.z;
+        // seeds from the camera-major arrays: the observations of one camera are sorted by point
+        // there, so neighbouring pairs of a block read neighbouring words (several per cache line)
+        Seed sa, sb;
+        sa.x = d.cm_sx[ja]; sa.y = d.cm_sy[ja]; sa.iz = d.cm_siz[ja];
+        sb.x = d.cm_sx[jb]; sb.y = d.cm_sy[jb]; sb.iz = d.cm_siz[jb];
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
         const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
         double aa[3], ab[3], ba[3], bb[3];
-        jac_pt(sa, d.K, camr.q, aa, ab);     // rows of Jp_a
-        jac_pt(sb, d.K, camc.q, ba, bb);     // rows of Jp_b
+        jac_pt(sa, d.K, qr, aa, ab);     // rows of Jp_a
+        jac_pt(sb, d.K, qc, ba, bb);     // rows of Jp_b
         // t0 = Vinv * ba, t1 = Vinv * bb  (Vinv packed upper: 00 01 02 11 12 22)
         const double t00 = v01.x * ba[0] + v01.y * ba[1] + v23.x * ba[2];
         const double t01 = v01.y * ba[0] + v23.y * ba[1] + v45.x * ba[2];
