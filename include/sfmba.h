@@ -170,6 +170,25 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d);
  * observations gets NaN, as np.mean([]) does. */
 int sfmba_reprojection_errors(sfmba_handle* h, double* mean_error, int64_t* n_observations);
 
+/* ---- the step that feeds bundle adjustment its initial points ---- */
+
+/* Two-view linear triangulation of n correspondences, batched: the replacement for
+ * cv.triangulatePoints + cv.convertPointsFromHomogeneous + the per-point error loop of
+ * triangulate_points (/root/reference/utils.py:176-211).  P1, P2 are the 3x4 projection
+ * matrices K [R | t] (row-major), x1, x2 are n x 2 pixel coordinates.  X receives n x 3
+ * points (right singular vector of the smallest singular value of the 4x4 DLT matrix,
+ * de-homogenised; a zero last coordinate divides by 1 as OpenCV does), err1 / err2 the
+ * reprojection error |x - dehom(P X)| of every point in either view
+ * (calculate_reprojection_error, utils.py:337-352).  err1 / err2 may be NULL.  Needs no problem. */
+int sfmba_triangulate(sfmba_handle* h, int64_t n, const double* P1, const double* P2,
+                      const double* x1, const double* x2, double* X, double* err1, double* err2);
+
+/* Reprojection errors of n given points in one view with projection matrix P (3x4, row-major):
+ * calculate_reprojection_error (utils.py:337-352) for a whole array, as the filters of
+ * store_3Dpoints_to_views (utils.py:279-315) and reproject_view (view.py:103-119) use it. */
+int sfmba_point_errors(sfmba_handle* h, int64_t n, const double* P, const double* X,
+                       const double* x, double* err);
+
 /* ---- diagnostics used by the parity tests: one linearisation at the current estimate ---- */
 
 /* Linearise and damp with lambda.  Afterwards the blocks below can be read. */

@@ -120,14 +120,35 @@ def nonortho_problem():
     return p
 
 
+def record_triangulation(name, n, seed, noise_px):
+    """Two-view fixture: inputs of triangulate_points (/root/reference/utils.py:176) and the
+    oracle's points and per-view reprojection errors.  Kept apart from the bundle-adjustment
+    fixtures by its ``tri_`` prefix."""
+    from oracle import triangulation_oracle as to
+    p = to.two_view_problem(n, seed=seed, noise_px=noise_px)
+    P1, P2 = to.projection(p["K"], p["R1"], p["t1"]), to.projection(p["K"], p["R2"], p["t2"])
+    X = to.triangulate(P1, P2, p["x1"], p["x2"])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), tri_K=p["K"], tri_R1=p["R1"], tri_t1=p["t1"],
+                        tri_R2=p["R2"], tri_t2=p["t2"], tri_x1=p["x1"], tri_x2=p["x2"], tri_X=X,
+                        tri_err1=to.reprojection_errors(P1, X, p["x1"]), tri_err2=to.reprojection_errors(P2, X, p["x2"]),
+                        tri_X_true=p["X_true"])
+    print(name, "mean errors", to.reprojection_errors(P1, X, p["x1"]).mean(), to.reprojection_errors(P2, X, p["x2"]).mean())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--triangulation-only" in sys.argv:
+        record_triangulation("tri_two_view_400", 400, seed=21, noise_px=0.5)
+        record_triangulation("tri_exact_64", 64, seed=22, noise_px=0.0)
+        return
     record("tiny_4_50_150", syn.make_problem(4, 50, 150, seed=1, window=4))
     record("rho2_11_300_600", syn.make_problem(11, 300, 600, seed=2))
     record("shuffled_9_200_700", syn.make_problem(9, 200, 700, seed=3, window=9, shuffle=True))
     record("nonortho_6_60_200", nonortho_problem())
     record("edge_5_13", edge_problem(), jac=False, solve=False, tight=False)   # FD across Z == 0 is meaningless
     record("ladybug_49_7776_31843", syn.make_shape("ladybug", seed=0), jac=False, tight_nfev=60)
+    record_triangulation("tri_two_view_400", 400, seed=21, noise_px=0.5)
+    record_triangulation("tri_exact_64", 64, seed=22, noise_px=0.0)
 
 
 if __name__ == "__main__":

@@ -1316,6 +1316,46 @@ int sfmba_reprojection_errors(sfmba_handle* h, double* mean_error, int64_t* n_ob
     });
 }
 
+int sfmba_triangulate(sfmba_handle* h, int64_t n, const double* P1, const double* P2,
+                      const double* x1, const double* x2, double* X, double* err1, double* err2) {
+    return guarded(h, [&] {
+        if (n < 0 || n > 2000000000LL || !P1 || !P2 || (n > 0 && (!x1 || !x2 || !X)))
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_triangulate: bad arguments");
+        if (n == 0) return;
+        HIP_TRY(hipSetDevice(h->device));
+        DBuf<double2> d1, d2;
+        DBuf<double> dX, de;
+        d1.alloc((size_t)n); d2.alloc((size_t)n); dX.alloc((size_t)3 * n); de.alloc((size_t)2 * n);
+        HIP_TRY(hipMemcpyAsync(d1.p, x1, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d2.p, x2, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+        launch_triangulate(P1, P2, (int)n, d1.p, d2.p, dX.p, de.p, de.p + n, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(X, dX.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (err1) HIP_TRY(hipMemcpyAsync(err1, de.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (err2) HIP_TRY(hipMemcpyAsync(err2, de.p + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_point_errors(sfmba_handle* h, int64_t n, const double* P, const double* X,
+                       const double* x, double* err) {
+    return guarded(h, [&] {
+        if (n < 0 || n > 2000000000LL || !P || (n > 0 && (!X || !x || !err)))
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_point_errors: bad arguments");
+        if (n == 0) return;
+        HIP_TRY(hipSetDevice(h->device));
+        DBuf<double2> dx;
+        DBuf<double> dX, de;
+        dx.alloc((size_t)n); dX.alloc((size_t)3 * n); de.alloc((size_t)n);
+        HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dX.p, X, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_reprojection_errors(P, (int)n, dX.p, dx.p, de.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(err, de.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
 int sfmba_linearize(sfmba_handle* h, double lambda) {
     return guarded(h, [&] {
         need_problem(h, "sfmba_linearize");

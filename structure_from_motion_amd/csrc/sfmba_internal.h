@@ -168,6 +168,10 @@ void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipSt
 void launch_schur_scale(const Dev& d, const FusedPcg& f, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
+// sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)
+void launch_triangulate(const double* P1, const double* P2, int n, const double2* x1, const double2* x2,
+                        double* X, double* err1, double* err2, hipStream_t st);
+void launch_reprojection_errors(const double* P, int n, const double* X, const double2* x, double* err, hipStream_t st);
 // sfmba_dense.hip
 int dense_padded(int n_real);
 void launch_dense_cholesky_solve(double* A, int n, int n_real, double* Linv_all, double* work, int* fail,

@@ -17,7 +17,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmba.s
 EXPORTS = (
     "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error",
     "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
-    "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_linearize", "sfmba_get_blocks",
+    "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_triangulate", "sfmba_point_errors",
+    "sfmba_linearize", "sfmba_get_blocks",
     "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_solve_step",
     "sfmba_comm_unique_id", "sfmba_comm_init",
     "sfmba_local_group_create", "sfmba_local_group_destroy", "sfmba_comm_init_local",
@@ -104,6 +105,8 @@ def load_library(path=None):
     lib.sfmba_solve.argtypes = [vp, C.POINTER(Stats)]
     lib.sfmba_get_params.argtypes = [vp, dp, dp]
     lib.sfmba_reprojection_errors.argtypes = [vp, dp, ip]
+    lib.sfmba_triangulate.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
+    lib.sfmba_point_errors.argtypes = [vp, C.c_int64, dp, dp, dp, dp]
     lib.sfmba_linearize.argtypes = [vp, C.c_double]
     lib.sfmba_get_blocks.argtypes = [vp, dp, dp, dp, dp]
     lib.sfmba_schur_matvec.argtypes = [vp, dp, dp]
@@ -242,6 +245,29 @@ class Engine:
         cnt = np.zeros(self.n_cameras, dtype=np.int64)
         self._check(self._lib.sfmba_reprojection_errors(self._h, _dp(mean), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return mean, cnt
+
+    def triangulate(self, P1, P2, x1, x2):
+        """Batched two-view linear triangulation: (X n x 3, err1, err2) for 3x4 projection matrices
+        P1, P2 and n x 2 pixel coordinates x1, x2 (see sfmba_triangulate)."""
+        P1 = _f64(P1).reshape(3, 4); P2 = _f64(P2).reshape(3, 4)
+        x1 = _f64(x1).reshape(-1, 2); x2 = _f64(x2).reshape(-1, 2)
+        n = x1.shape[0]
+        if x2.shape[0] != n:
+            raise ValueError("x1 and x2 must hold the same number of points")
+        X = np.empty((n, 3)); e1 = np.empty(n); e2 = np.empty(n)
+        self._check(self._lib.sfmba_triangulate(self._h, n, _dp(P1), _dp(P2), _dp(x1), _dp(x2), _dp(X), _dp(e1), _dp(e2)))
+        return X, e1, e2
+
+    def point_errors(self, P, X, x):
+        """Reprojection error of every point X[i] against x[i] under the 3x4 projection matrix P."""
+        P = _f64(P).reshape(3, 4)
+        X = _f64(X).reshape(-1, 3); x = _f64(x).reshape(-1, 2)
+        n = X.shape[0]
+        if x.shape[0] != n:
+            raise ValueError("X and x must hold the same number of points")
+        e = np.empty(n)
+        self._check(self._lib.sfmba_point_errors(self._h, n, _dp(P), _dp(X), _dp(x), _dp(e)))
+        return e
 
     # -- diagnostics
     def linearize(self, lam):
