@@ -385,7 +385,7 @@ void reduce_scalars(H* h, int first, int count) {
 void phase_linearize(H* h) {
     Scope t(h, F_LIN);
     refresh_dev(h);
-    launch_lin_pm(h->dev, h->stream);
+    launch_lin_pm(h->dev, !h->explicit_schur, h->stream);
     launch_lin_cm(h->dev, h->stream);
     launch_chunk_reduce(h->dev, 27, h->UG.p, h->stream);
     if (h->has_comm()) {
@@ -580,12 +580,8 @@ int phase_linear_solve(H* h, double lambda) {
 void phase_trial(H* h, double* dp_out) {
     {
         Scope t(h, F_BACK);
-        launch_back_pm(h->dev, h->px.p, dp_out, h->stream);
-        launch_cam_update(h->dev, h->px.p, h->stream);
-    }
-    {
-        Scope t(h, F_COST);
-        launch_cost_pm(h->dev, h->stream);
+        launch_cam_update(h->dev, h->px.p, h->stream);          // the trial cameras first:
+        launch_back_pm(h->dev, h->px.p, dp_out, h->stream);     // this pass also evaluates the trial cost
     }
     reduce_scalars(h, SLOT_MODEL, SLOT_NONFINITE - SLOT_MODEL + 1);
 }
@@ -1071,8 +1067,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->pm_orig.upload(pm_orig, st); h->pm_uv.upload(pm_uv, st);
     h->cm_pt.upload(cm_pt, st); h->cm_uv.upload(cm_uv, st);
     h->chunk_cam.upload(chunk_cam, st); h->chunk_beg.upload(chunk_beg, st); h->cam_chunk_ptr.upload(cam_chunk_ptr, st);
-    for (DBuf<double>* b : {&h->pm_rv, &h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
-    h->pm_seed.alloc((size_t)no);
+    for (DBuf<double>* b : {&h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
     {   // wave tiles of the point-major order: whole points, <= 64 observations (or one long point)
         std::vector<int> wt;
         int beg = 0;
@@ -1105,6 +1100,8 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         h->pcg.alloc(2); h->dot_part.alloc((size_t)h->dot_off + pcg_update_blocks(t));
     }
     build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm2cm);
+    if (h->explicit_schur) { h->pm_seed.release(); h->pm_rv.release(); }     // only the matrix-free product reads them
+    else { h->pm_seed.alloc((size_t)no); h->pm_rv.alloc((size_t)no); }
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
     h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
     h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * 36));

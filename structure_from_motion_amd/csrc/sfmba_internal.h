@@ -127,7 +127,7 @@ struct Dev {
 // ---- launch wrappers (sfmba_kernels.hip) -------------------------------------------------
 void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);
 void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStream_t st);
-void launch_lin_pm(const Dev& d, hipStream_t st);
+void launch_lin_pm(const Dev& d, bool store_seeds, hipStream_t st);   // seeds are only stored for the matrix-free Schur product
 void launch_lin_cm(const Dev& d, hipStream_t st);               // chunk partials (27 values)
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);
@@ -153,7 +153,6 @@ hipError_t launch_pcg_fused(const FusedPcg& f, int blocks, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
-void launch_cost_pm(const Dev& d, hipStream_t st);
 void launch_gmax_cam(const Dev& d, hipStream_t st);
 void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st);   // [n_cam][2] = (sum of errors, count)
 int scal_blocks_pt(const Dev& d);

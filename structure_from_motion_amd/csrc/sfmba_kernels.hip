@@ -73,7 +73,10 @@ __device__ __forceinline__ Tile wave_tile(const Dev& d) {
     return t;
 }
 
-// Linearisation, point-major half: seeds + residuals per observation, V_p and g_p per point.
+// Linearisation, point-major half: V_p and g_p per point, cost and gradient maximum; with kStore
+// also the seeds + residuals per observation, which only the matrix-free Schur product reads
+// (every other consumer rebuilds them from X and the camera it gathers anyway).
+template <bool kStore>
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
     __shared__ double red[16];
     const int lane = threadIdx.x & 63;
@@ -90,8 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
         const double2 uv = d.pm_uv[j];
         double ru, rv;
         residual(s, d.K, uv.x, uv.y, ru, rv);
-        d.pm_seed[j] = make_double4(s.x, s.y, s.iz, ru);
-        d.pm_rv[j] = rv;
+        if (kStore) {
+            d.pm_seed[j] = make_double4(s.x, s.y, s.iz, ru);
+            d.pm_rv[j] = rv;
+        }
         double a[3], b[3];
         jac_pt(s, d.K, k.q, a, b);
         acc[0] += a[0] * a[0] + b[0] * b[0];
@@ -391,19 +396,32 @@ __global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __r
 
 // ------------------------------------------------------------------------------------------
 // Back-substitution per point: dp = -Vinv (g_p + sum Jp' Jc dc); X_trial = X + dp; the cost of
-// the linear model at the step; |dp|^2 and |X|^2.
-struct BackObs { Seed s; double ru, rv, w0, w1; Cam k; };
-__device__ __forceinline__ BackObs back_load(const Dev& d, const double* __restrict__ dc, int j) {
+// the linear model at the step; |dp|^2 and |X|^2; and, in the same pass, the cost at the trial
+// point (X_trial with the retracted cameras, which k_cam_update must have written): every lane
+// holds its observation, its point's step and gathers its camera anyway.  Seeds and residuals at
+// the linearisation point are rebuilt from X and the camera rather than read back.
+struct BackObs { Seed s; double ru, rv, w0, w1; Cam k; double2 uv; int c; };
+__device__ __forceinline__ BackObs back_load(const Dev& d, const double* __restrict__ dc, int j, const double4& X) {
     BackObs o;
-    const int c = d.pm_cam[j];
-    const double4 sd = d.pm_seed[j];
-    o.s.x = sd.x; o.s.y = sd.y; o.s.iz = sd.z; o.ru = sd.w; o.rv = d.pm_rv[j];
-    const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)c);
+    o.c = d.pm_cam[j];
+    o.uv = d.pm_uv[j];
+    o.k = load_cam(d.cams, o.c);
+    o.s = project_seed(o.k, X.x, X.y, X.z);
+    residual(o.s, d.K, o.uv.x, o.uv.y, o.ru, o.rv);
+    const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)o.c);
     const double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
     const double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
     jc_times(o.s, d.K, dd, o.w0, o.w1);
-    o.k = load_cam(d.cams, c);
     return o;
+}
+// squared residual of observation o at the trial point; non-finite values are counted instead
+__device__ __forceinline__ void trial_cost(const Dev& d, const BackObs& o, const Cam& kt, const double4& X, const double* dp,
+                                           double& cost, double& bad) {
+    const Seed st = project_seed(kt, X.x + dp[0], X.y + dp[1], X.z + dp[2]);
+    double ru, rv;
+    residual(st, d.K, o.uv.x, o.uv.y, ru, rv);
+    const double e = ru * ru + rv * rv;
+    if (isfinite(e)) cost += e; else bad += 1.0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
@@ -411,13 +429,26 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     __shared__ double red[16];
     const int lane = threadIdx.x & 63;
     const Tile t = wave_tile(d);
-    double model = 0.0, step2 = 0.0, x2 = 0.0;
+    double model = 0.0, step2 = 0.0, x2 = 0.0, trial = 0.0, bad = 0.0;
     double e[3] = {0, 0, 0};
     int key = -1 - lane;
     BackObs o{};
+    double4 X = make_double4(0.0, 0.0, 0.0, 0.0);
+    // everything the lane will need after the segmented sum is requested up front, so that the
+    // scan does not sit between two rounds of memory latency
+    double4 g = make_double4(0.0, 0.0, 0.0, 0.0);
+    double2 v01 = make_double2(0.0, 0.0), v23 = v01, v45 = v01;
+    Cam kt{};
     for (int j = t.beg + lane; j < t.end; j += 64) {
         key = d.pm_pt[j];
-        o = back_load(d, dc, j);
+        X = d.X[key];
+        if (!t.is_long) {
+            g = *reinterpret_cast<const double4*>(d.gp + 4 * (size_t)key);
+            const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
+            v01 = vi[0]; v23 = vi[1]; v45 = vi[2];
+        }
+        o = back_load(d, dc, j, X);
+        if (!t.is_long) kt = load_cam(d.cams_trial, o.c);
         jpT_times_acc(o.s, d.K, o.k.q, o.w0, o.w1, e);
     }
     bool writer;
@@ -426,6 +457,12 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
         for (int i = 0; i < 3; ++i) e[i] = wave_sum(e[i]);
         key = __shfl(key, 0, 64);
         writer = lane == 0;
+        if (key >= 0) {
+            X = d.X[key];
+            g = *reinterpret_cast<const double4*>(d.gp + 4 * (size_t)key);
+            const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
+            v01 = vi[0]; v23 = vi[1]; v45 = vi[2];
+        }
     } else {
         seg_scan(e, key, lane);
         const int last = seg_last(key, lane);
@@ -435,16 +472,12 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     }
     double dp[3] = {0, 0, 0};
     if (key >= 0) {
-        const double* g = d.gp + 4 * (size_t)key;
-        const double t0 = e[0] + g[0], t1 = e[1] + g[1], t2 = e[2] + g[2];
-        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
-        const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        const double t0 = e[0] + g.x, t1 = e[1] + g.y, t2 = e[2] + g.z;
         dp[0] = -(v01.x * t0 + v01.y * t1 + v23.x * t2);
         dp[1] = -(v01.y * t0 + v23.y * t1 + v45.x * t2);
         dp[2] = -(v23.x * t0 + v45.x * t1 + v45.y * t2);
     }
     if (writer) {
-        const double4 X = d.X[key];
         d.X_trial[key] = make_double4(X.x + dp[0], X.y + dp[1], X.z + dp[2], 0.0);
         if (dp_out) { dp_out[3 * (size_t)key] = dp[0]; dp_out[3 * (size_t)key + 1] = dp[1]; dp_out[3 * (size_t)key + 2] = dp[2]; }
         step2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
@@ -452,25 +485,32 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     }
     if (t.is_long) {
         for (int j = t.beg + lane; j < t.end; j += 64) {
-            const BackObs b = back_load(d, dc, j);
+            const BackObs b = back_load(d, dc, j, X);
+            const Cam kt = load_cam(d.cams_trial, b.c);
             double u0, u1;
             jp_times(b.s, d.K, b.k.q, dp, u0, u1);
             const double l0 = b.ru + b.w0 + u0, l1 = b.rv + b.w1 + u1;
             model += l0 * l0 + l1 * l1;
+            trial_cost(d, b, kt, X, dp, trial, bad);
         }
     } else if (key >= 0) {
         double u0, u1;
         jp_times(o.s, d.K, o.k.q, dp, u0, u1);
         const double l0 = o.ru + o.w0 + u0, l1 = o.rv + o.w1 + u1;
         model = l0 * l0 + l1 * l1;
+        trial_cost(d, o, kt, X, dp, trial, bad);
     }
     const double a = block_sum(model, red);
     const double b = block_sum(step2, red);
     const double c2 = block_sum(x2, red);
+    const double tr = block_sum(trial, red);
+    const double nf = block_sum(bad, red);
     if (threadIdx.x == 0) {
         put_partial(d, SLOT_MODEL, a);
         put_partial(d, SLOT_STEP2_PT, b);
         put_partial(d, SLOT_X2_PT, c2);
+        put_partial(d, SLOT_TRIAL, tr);
+        put_partial(d, SLOT_NONFINITE, nf);
     }
 }
 
@@ -502,26 +542,6 @@ __global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __re
     double a = block_sum(step2, red);
     double b = block_sum(x2, red);
     if (threadIdx.x == 0) { put_partial(d, SLOT_STEP2_CAM, a); put_partial(d, SLOT_X2_CAM, b); }
-}
-
-// Cost at the trial point (cams_trial, X_trial): one thread per observation.
-__global__ __launch_bounds__(kBlock) void k_cost_pm(Dev d) {
-    __shared__ double red[16];
-    const int j = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    double cost = 0.0, bad = 0.0;
-    if (j < d.n_obs) {
-        const double4 X = d.X_trial[d.pm_pt[j]];
-        const Cam k = load_cam(d.cams_trial, d.pm_cam[j]);
-        const Seed s = project_seed(k, X.x, X.y, X.z);
-        const double2 uv = d.pm_uv[j];
-        double ru, rv;
-        residual(s, d.K, uv.x, uv.y, ru, rv);
-        const double e = ru * ru + rv * rv;
-        if (isfinite(e)) cost = e; else bad = 1.0;
-    }
-    const double a = block_sum(cost, red);
-    const double b = block_sum(bad, red);
-    if (threadIdx.x == 0) { put_partial(d, SLOT_TRIAL, a); put_partial(d, SLOT_NONFINITE, b); }
 }
 
 // scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per slot.
@@ -594,7 +614,6 @@ void launch_vec_add(double* a, const double* b, size_t n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
 static int blocks_wtile(const Dev& d) { return cdiv(d.n_wtiles, kBlock / 64); }
-static int blocks_obs(const Dev& d) { return cdiv(d.n_obs, kBlock); }
 int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
 
 
@@ -606,9 +625,12 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     if (d.n_obs == 0) return;
     hipLaunchKernelGGL(k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, jc, jp);
 }
-void launch_lin_pm(const Dev& d, hipStream_t st) {
+void launch_lin_pm(const Dev& d, bool store_seeds, hipStream_t st) {
     const int nb = blocks_wtile(d);
-    if (nb > 0) hipLaunchKernelGGL(k_lin_pm, dim3(nb), dim3(kBlock), 0, st, d);
+    if (nb > 0) {
+        if (store_seeds) hipLaunchKernelGGL(k_lin_pm<true>, dim3(nb), dim3(kBlock), 0, st, d);
+        else hipLaunchKernelGGL(k_lin_pm<false>, dim3(nb), dim3(kBlock), 0, st, d);
+    }
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
 }
 void launch_lin_cm(const Dev& d, hipStream_t st) {
@@ -643,16 +665,11 @@ void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y,
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st) {
     const int nb = blocks_wtile(d);
     if (nb > 0) hipLaunchKernelGGL(k_back_pm, dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(3), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(5), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u);     // MODEL .. NONFINITE
 }
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st) {
     hipLaunchKernelGGL(k_cam_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, dc);
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_STEP2_CAM, blocks_cam(d), 0u);
-}
-void launch_cost_pm(const Dev& d, hipStream_t st) {
-    const int nb = blocks_obs(d);
-    if (nb > 0) hipLaunchKernelGGL(k_cost_pm, dim3(nb), dim3(kBlock), 0, st, d);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_TRIAL, nb, 0u);
 }
 
 }  // namespace sfmba
