@@ -276,6 +276,60 @@ __device__ __forceinline__ double block_max(double v, double* scratch) {
     return r;
 }
 
+// Reduce N per-thread values over the workgroup (4 wavefronts) with ONE workgroup barrier and no
+// shuffle chains: every lane stores its values as a row of its wavefront's LDS tile, 8 N lanes
+// add 8 rows each for one value, N lanes add the 8 parts, and after the barrier thread i < N adds
+// the four wavefront results of value i.  Bit i of max_mask selects a maximum (of non-negative
+// values) instead of a sum for value i.  The order of the operations is fixed.  `scratch` holds
+// 4 * (64 N + 8 N) + 4 N doubles; thread i < N returns the result of value i, others 0.
+template <int N>
+__device__ __forceinline__ double block_reduce_n(const double (&v)[N], unsigned max_mask, double* scratch) {
+    static_assert(8 * N <= 64, "one lane per (value, part)");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* tile = scratch + w * (72 * N);
+    double* parts = tile + 64 * N;
+    double* red = scratch + 4 * (72 * N);
+#pragma unroll
+    for (int i = 0; i < N; ++i) tile[lane * N + i] = v[i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8 * N) {
+        const int k = lane % N, part = lane / N;
+        const bool is_max = (max_mask >> k) & 1u;
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const double x = tile[(8 * part + r) * N + k];
+            a = is_max ? fmax(a, x) : a + x;
+        }
+        parts[lane] = a;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < N) {
+        const bool is_max = (max_mask >> lane) & 1u;
+        double a = 0.0;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const double x = parts[p8 * N + lane];
+            a = is_max ? fmax(a, x) : a + x;
+        }
+        red[w * N + lane] = a;
+    }
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.x < N) {
+        const bool is_max = (max_mask >> threadIdx.x) & 1u;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const double x = red[ww * N + threadIdx.x];
+            out = is_max ? fmax(out, x) : out + x;
+        }
+    }
+    return out;
+}
+template <int N> constexpr int block_reduce_scratch() { return 4 * (72 * N) + 4 * N; }
+
 // Sum N per-lane values over the 64 lanes through a per-wave LDS tile instead of log-step
 // shuffles: in passes of H values every lane stores its H values as one row (row stride H+2
 // doubles, 16-byte aligned), then lane e < H adds column e over the 64 rows.  After the call

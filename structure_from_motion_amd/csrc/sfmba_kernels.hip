@@ -78,7 +78,7 @@ __device__ __forceinline__ Tile wave_tile(const Dev& d) {
 // (every other consumer rebuilds them from X and the camera it gathers anyway).
 template <bool kStore>
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
-    __shared__ double red[16];
+    __shared__ double red[block_reduce_scratch<2>()];
     const int lane = threadIdx.x & 63;
     const Tile t = wave_tile(d);
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -127,9 +127,10 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
         go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
         gmax = fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8])));
     }
-    const double c = block_sum(cost, red);
-    const double m = block_max(gmax, red);
-    if (threadIdx.x == 0) { put_partial(d, SLOT_COST, c); put_partial(d, SLOT_GMAX_PT, m); }
+    static_assert(SLOT_GMAX_PT == SLOT_COST + 1, "slot order");
+    const double vals[2] = {cost, gmax};
+    const double r = block_reduce_n<2>(vals, 2u, red);
+    if (threadIdx.x < 2) put_partial(d, SLOT_COST + threadIdx.x, r);
 }
 
 // Linearisation, camera-major half: seeds per observation (camera-major copy) and the chunk
@@ -426,7 +427,7 @@ __device__ __forceinline__ void trial_cost(const Dev& d, const BackObs& o, const
 
 __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
                                                     double* __restrict__ dp_out) {
-    __shared__ double red[16];
+    __shared__ double red[block_reduce_scratch<5>()];
     const int lane = threadIdx.x & 63;
     const Tile t = wave_tile(d);
     double model = 0.0, step2 = 0.0, x2 = 0.0, trial = 0.0, bad = 0.0;
@@ -500,18 +501,11 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
         model = l0 * l0 + l1 * l1;
         trial_cost(d, o, kt, X, dp, trial, bad);
     }
-    const double a = block_sum(model, red);
-    const double b = block_sum(step2, red);
-    const double c2 = block_sum(x2, red);
-    const double tr = block_sum(trial, red);
-    const double nf = block_sum(bad, red);
-    if (threadIdx.x == 0) {
-        put_partial(d, SLOT_MODEL, a);
-        put_partial(d, SLOT_STEP2_PT, b);
-        put_partial(d, SLOT_X2_PT, c2);
-        put_partial(d, SLOT_TRIAL, tr);
-        put_partial(d, SLOT_NONFINITE, nf);
-    }
+    static_assert(SLOT_STEP2_PT == SLOT_MODEL + 1 && SLOT_X2_PT == SLOT_MODEL + 2 && SLOT_TRIAL == SLOT_MODEL + 3 &&
+                  SLOT_NONFINITE == SLOT_MODEL + 4, "slot order");
+    const double vals[5] = {model, step2, x2, trial, bad};
+    const double r = block_reduce_n<5>(vals, 0u, red);
+    if (threadIdx.x < 5) put_partial(d, SLOT_MODEL + threadIdx.x, r);
 }
 
 // Camera retraction: Q' = exp([dw]x) Q, t' = exp([dw]x) t + dt.

@@ -11,7 +11,8 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmba.so")
+# SFMBA_LIBRARY selects another build of the same library (A/B measurements of kernel variants)
+_LIB_PATH = os.environ.get("SFMBA_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsfmba.so")
 
 # every symbol include/sfmba.h declares
 EXPORTS = (
