@@ -231,7 +231,7 @@ struct sfmba_handle {
     bool explicit_schur = false;
     int n_ublk = 0, n_pchunks = 0, nnzb = 0, nb_bsr = 0, dot_off = 0;
     int64_t n_pairs = 0;
-    DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, pchunk_blk, pchunk_beg;
+    DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg;
     DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
     DBuf<double> pair_part, Bsum, Sfull;
     // single-launch PCG on the scaled system
@@ -297,7 +297,7 @@ void refresh_dev(H* h) {
     d.dot_off = h->dot_off;
     d.n_ublk = h->n_ublk; d.n_pchunks = h->n_pchunks; d.nnzb = h->nnzb;
     d.ublk_r = h->ublk_r.p; d.ublk_c = h->ublk_c.p; d.ublk_chunk_ptr = h->ublk_chunk_ptr.p;
-    d.ublk_pos = h->ublk_pos.p; d.ublk_pos_t = h->ublk_pos_t.p;
+    d.ublk_pos = h->ublk_pos.p; d.ublk_pos_t = h->ublk_pos_t.p; d.ublk_diag = h->ublk_diag.p;
     d.pchunk_blk = h->pchunk_blk.p; d.pchunk_beg = h->pchunk_beg.p;
     d.pair_a = h->pair_a.p; d.pair_b = h->pair_b.p; d.pair_p = h->pair_p.p;
     d.pair_part = h->pair_part.p; d.Bsum = h->Bsum.p;
@@ -427,8 +427,7 @@ void phase_damp(H* h, double lambda) {
         allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36 + (size_t)h->n_cam * 6);
         {
             Scope t(h, F_SCHUR);
-            launch_schur_finish(h->dev, lambda, bpart, h->stream);
-            if (h->fused_pcg) launch_schur_scale(h->dev, h->fused, h->stream);
+            launch_schur_finish(h->dev, lambda, bpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
         }
     } else {
         Scope t(h, F_DAMP);
@@ -912,6 +911,10 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     hipStream_t st = h->stream;
     h->ublk_r.upload(ur, st); h->ublk_c.upload(uc, st); h->ublk_chunk_ptr.upload(ublk_chunk_ptr, st);
     h->ublk_pos.upload(upos, st); h->ublk_pos_t.upload(upos_t, st);
+    {
+        std::vector<int> udiag(urow_ptr.begin(), urow_ptr.end() - 1);      // (c, c) is the first upper block of row c
+        h->ublk_diag.upload(udiag, st);
+    }
     h->pchunk_blk.upload(pchunk_blk, st); h->pchunk_beg.upload(pchunk_beg, st);
     h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
     h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);

@@ -112,6 +112,7 @@ struct Dev {
     int nnzb;                 // blocks of the full block-CSR matrix
     const int* ublk_r; const int* ublk_c;         // [n_ublk]
     const int* ublk_chunk_ptr;                    // [n_ublk+1] pair-chunk range of each upper block
+    const int* ublk_diag;                         // [n_cam] upper block (c, c) of every camera
     const int* ublk_pos; const int* ublk_pos_t;   // [n_ublk] slots of (r,c) and (c,r) in Sfull
     const int* pchunk_blk; const int* pchunk_beg; // [n_pchunks], [n_pchunks+1]
     const int* pair_a; const int* pair_b; const int* pair_p;   // [n_pairs] camera-major indices of the two observations, point
@@ -162,9 +163,8 @@ int blocks_cam(const Dev& d);
 int bsr_blocks(const Dev& d);
 void launch_schur_pairs(const Dev& d, hipStream_t st);
 void launch_block_reduce(const Dev& d, hipStream_t st);
-void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st);
-// scaled system for the single-launch PCG: F, bhat, Shat; also clears the barrier words
-void launch_schur_scale(const Dev& d, const FusedPcg& f, hipStream_t st);
+// full matrix, preconditioner, right-hand side; with `scaled` also F, bhat, Shat of the single-launch PCG
+void launch_schur_finish(const Dev& d, double lambda, const double* bpart, const FusedPcg* scaled, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)

@@ -95,57 +95,117 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d) {
     d.Bsum[i] = s;
 }
 
-// Full block-CSR S from the (all-ranks) upper sums: S_rc = -B, S_cr = -B', S_rr = U*_r - B.
-__global__ __launch_bounds__(kBlock) void k_schur_finish(Dev d, double lambda) {
+// Finishing passes over the (all-ranks) upper sums B: S_rc = -B, S_cr = -B', S_cc = U*_c - B_cc.
+//
+// k_finish_diag, one thread per camera: the diagonal block of the full block-CSR matrix, its
+// Cholesky factor, the inverse (block-Jacobi preconditioner), the reduced right-hand side
+// rhs = -g_c + sum W Vinv g_p and, for the single-launch PCG, the scaling F = L^-1, bhat = F rhs
+// and the scaled diagonal block F S_cc F'.
+__global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, const double* __restrict__ bpart, FusedPcg f) {
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= d.n_cam) return;
+    const double* U = d.UG + 27 * (size_t)c;
+    const double* B = d.Bsum + 36 * (size_t)d.ublk_diag[c];
+    double S[6][6], A[6][6], Li[6][6], Ai[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int a = i < j ? i : j, b = i < j ? j : i;
+            double uv = U[upidx(6, a, b)];
+            if (i == j) uv += lambda * fmin(fmax(uv, 1e-6), 1e32);
+            S[i][j] = uv - B[6 * i + j];
+            Li[i][j] = 0.0;
+        }
+    double* So = d.Sfull + 36 * (size_t)d.bsr_diag[c];
+    double dg[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        dg[i] = S[i][i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { So[6 * i + j] = S[i][j]; A[i][j] = 0.5 * (S[i][j] + S[j][i]); }
+    }
+    const bool ok = spd6_inverse(A, Ai, Li);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                Ai[i][j] = (i == j) ? 1.0 / fmax(fabs(dg[i]), 1e-300) : 0.0;
+                Li[i][j] = (i == j) ? 1.0 / sqrt(fmax(fabs(dg[i]), 1e-300)) : 0.0;
+            }
+    }
+    double* Mo = d.Minv + 36 * (size_t)c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Mo[6 * i + j] = Ai[i][j];
+    const double* g = U + 21;
+    double r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        r[i] = -g[i] + bpart[6 * (size_t)c + i];
+        d.rhs[6 * (size_t)c + i] = r[i];
+    }
+    if (f.F == nullptr) return;
+    double* Fo = const_cast<double*>(f.F) + 36 * (size_t)c;
+    double* bo = const_cast<double*>(f.bhat) + 6 * (size_t)c;
+    double T[6][6];                 // F S
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double lij = j <= i ? Li[i][j] : 0.0;
+            Fo[6 * i + j] = lij;
+            v += lij * r[j];
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) t += Li[i][k] * S[k][j];
+            T[i][j] = t;
+        }
+        bo[i] = v;
+    }
+    double* Ho = const_cast<double*>(f.Shat) + 36 * (size_t)d.bsr_diag[c];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l <= j; ++l) v += T[i][l] * Li[j][l];
+            Ho[6 * i + j] = v;
+        }
+}
+
+// k_finish_offdiag, one thread per element of every upper off-diagonal block: both orientations
+// of the block in the full matrix and, for the single-launch PCG, of the scaled block
+// F_r S_rc F_c' (its transpose is the scaled S_cr).
+__global__ __launch_bounds__(kBlock) void k_finish_offdiag(Dev d, FusedPcg f) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= d.n_ublk * 36) return;
     const int u = t / 36, e = t - 36 * u, i = e / 6, j = e - 6 * i;
     const int r = d.ublk_r[u], c = d.ublk_c[u];
-    double v = -d.Bsum[t];
-    if (r == c) {
-        const double* U = d.UG + 27 * (size_t)r;
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        double uv = U[upidx(6, a, b)];
-        if (i == j) uv += lambda * fmin(fmax(uv, 1e-6), 1e32);
-        d.Sfull[36 * (size_t)d.ublk_pos[u] + e] = uv + v;
-    } else {
-        d.Sfull[36 * (size_t)d.ublk_pos[u] + e] = v;
-        d.Sfull[36 * (size_t)d.ublk_pos_t[u] + 6 * j + i] = v;
+    if (r == c) return;
+    const size_t pos = 36 * (size_t)d.ublk_pos[u] + e, pos_t = 36 * (size_t)d.ublk_pos_t[u] + 6 * j + i;
+    const double v = -d.Bsum[t];
+    d.Sfull[pos] = v;
+    d.Sfull[pos_t] = v;
+    if (f.F == nullptr) return;
+    const double* Fi = f.F + 36 * (size_t)r + 6 * i;
+    const double* Fj = f.F + 36 * (size_t)c + 6 * j;
+    const double* B = d.Bsum + 36 * (size_t)u;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double tk = 0.0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) tk += B[6 * k + l] * Fj[l];
+        s += Fi[k] * tk;
     }
-}
-
-// Inverse of the diagonal blocks of S (block-Jacobi preconditioner), reduced right-hand side
-// rhs = -g_c + sum W Vinv g_p, and the gradient maximum.  One thread per camera.
-__global__ __launch_bounds__(kBlock) void k_precond_explicit(Dev d, double lambda, const double* __restrict__ bpart) {
-    __shared__ double red[16];
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    double gmax = 0.0;
-    if (c < d.n_cam) {
-        const double* S = d.Sfull + 36 * (size_t)d.bsr_diag[c];
-        double A[6][6], Ai[6][6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) A[i][j] = 0.5 * (S[6 * i + j] + S[6 * j + i]);
-        double dg[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dg[i] = A[i][i];
-        const bool ok = spd6_inverse(A, Ai);
-        double* o = d.Minv + 36 * (size_t)c;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) o[6 * i + j] = ok ? Ai[i][j] : ((i == j) ? 1.0 / fmax(fabs(dg[i]), 1e-300) : 0.0);
-        const double* g = d.UG + 27 * (size_t)c + 21;
-        double* rr = d.rhs + 6 * (size_t)c;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            rr[i] = -g[i] + bpart[6 * (size_t)c + i];
-            gmax = fmax(gmax, fabs(g[i]));
-        }
-    }
-    (void)gmax;
-    (void)red;
+    double* H = const_cast<double*>(f.Shat);
+    H[pos] = -s;
+    H[pos_t] = -s;
 }
 
 // y = S x on the block-CSR matrix, one thread per (camera, row of the block); 42 cameras per
@@ -183,67 +243,8 @@ __global__ __launch_bounds__(kBlock) void k_bsr_to_dense(Dev d, double* __restri
     A[(size_t)row * n + col] = d.Sfull[t];
 }
 
-// F = L^-1 of every diagonal block (S_cc = L L') and bhat = F rhs; one thread per camera.
-__global__ __launch_bounds__(kBlock) void k_scale_factors(Dev d, FusedPcg f) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= d.n_cam) return;
-    const double* S = d.Sfull + 36 * (size_t)d.bsr_diag[c];
-    double A[6][6], Li[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { A[i][j] = 0.5 * (S[6 * i + j] + S[6 * j + i]); Li[i][j] = 0.0; }
-    double dg[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dg[i] = A[i][i];
-    const bool ok = spd6_chol_linv(A, Li);
-    double* o = const_cast<double*>(f.F) + 36 * (size_t)c;
-    double b[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = d.rhs[6 * (size_t)c + i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double lij = ok ? (j <= i ? Li[i][j] : 0.0) : (i == j ? 1.0 / sqrt(fmax(fabs(dg[i]), 1e-300)) : 0.0);
-            o[6 * i + j] = lij;
-            v += lij * b[j];
-        }
-        const_cast<double*>(f.bhat)[6 * (size_t)c + i] = v;
-    }
-}
-
-// Shat_b = F_row S_b F_col'; one thread per (block, element).
-__global__ __launch_bounds__(kBlock) void k_scale_blocks(Dev d, FusedPcg f) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= d.nnzb * 36) return;
-    const int b = t / 36, e = t - 36 * b, i = e / 6, j = e - 6 * i;
-    int lo = 0, hi = d.n_cam;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (d.bsr_ptr[mid] <= b) lo = mid; else hi = mid;
-    }
-    const double* Fi = f.F + 36 * (size_t)lo + 6 * i;
-    const double* Fj = f.F + 36 * (size_t)d.bsr_col[b] + 6 * j;
-    const double* S = d.Sfull + 36 * (size_t)b;
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        double tk = 0.0;
-#pragma unroll
-        for (int l = 0; l < 6; ++l) tk += S[6 * k + l] * Fj[l];
-        v += Fi[k] * tk;
-    }
-    const_cast<double*>(f.Shat)[t] = v;
-}
-
 int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerBlock); }
 
-void launch_schur_scale(const Dev& d, const FusedPcg& f, hipStream_t st) {
-    hipLaunchKernelGGL(k_scale_factors, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, f);
-    hipLaunchKernelGGL(k_scale_blocks, dim3(cdiv(d.nnzb * 36, kBlock)), dim3(kBlock), 0, st, d, f);
-}
 
 void launch_schur_pairs(const Dev& d, hipStream_t st) {
     if (d.n_pchunks > 0)
@@ -253,10 +254,12 @@ void launch_block_reduce(const Dev& d, hipStream_t st) {
     if (d.n_ublk > 0)
         hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d);
 }
-void launch_schur_finish(const Dev& d, double lambda, const double* bpart, hipStream_t st) {
+void launch_schur_finish(const Dev& d, double lambda, const double* bpart, const FusedPcg* scaled, hipStream_t st) {
+    FusedPcg f{};
+    if (scaled) f = *scaled;
+    hipLaunchKernelGGL(k_finish_diag, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, bpart, f);
     if (d.n_ublk > 0)
-        hipLaunchKernelGGL(k_schur_finish, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d, lambda);
-    hipLaunchKernelGGL(k_precond_explicit, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, bpart);
+        hipLaunchKernelGGL(k_finish_offdiag, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d, f);
 }
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st) {
     hipLaunchKernelGGL(k_bsr_spmv, dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y);
