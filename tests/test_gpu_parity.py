@@ -229,6 +229,37 @@ def test_single_launch_pcg_zero_right_hand_side_and_iteration_cap():
     assert np.abs(dc).max() < 1e-6 and np.abs(dp).max() < 1e-6
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
+def test_rejected_steps_raise_the_damping_and_recover(solver):
+    # a start far from the optimum with almost no damping: several steps are rejected, the damping
+    # grows without a new linearisation, and every PCG path ends at the same minimum
+    p = syn.make_problem(12, 300, 1500, seed=4, window=8, point_sigma=0.8, rot_sigma=0.3, trans_sigma=0.5)
+    with make_engine(p, initial_lambda=1e-12, ftol=1e-10, **SOLVERS[solver]) as eng:
+        st = eng.solve()
+    assert st.status in (1, 2, 3, 4)
+    assert st.iterations > st.accepted >= 5            # rejections happened
+    assert st.njev == st.accepted + 1                  # no linearisation for a rejected step
+    assert st.final_cost <= 1e-3 * st.initial_cost
+    if solver != "dense":      # the exact steps of the factorisation end in another local minimum
+        assert abs(st.final_cost - 242.118732038) <= 1e-6 * 242.118732038
+
+
+def test_unobserved_camera_and_point_stay_where_they_are():
+    g = load_golden("tiny_4_50_150")
+    cp = np.vstack([g["camera_params"], g["camera_params"][:1] + 0.25])      # camera 4: no observations
+    pts = np.vstack([g["points_3d"], [[7.0, -3.0, 2.0]]])                    # point 50: no observations
+    for solver in SOLVERS.values():
+        with Engine(**solver) as eng:
+            eng.set_problem(cp, pts, g["camera_indices"], g["point_indices"], g["points_2d"], g["K"])
+            st = eng.solve()
+            poses, X = eng.get_params()
+            err, cnt = eng.reprojection_errors()
+        assert st.status in (1, 2, 3, 4) and np.isfinite(st.final_cost)
+        assert np.array_equal(X[50], pts[50])
+        assert np.allclose(poses[4, 9:], cp[4, 9:], rtol=0, atol=1e-12)
+        assert cnt[4] == 0 and np.isnan(err[4])
+
+
 def test_dense_cholesky_is_the_fallback_when_pcg_runs_out_of_iterations():
     g = load_golden("shuffled_9_200_700")
     with make_engine(g, pcg_max_iter=1, pcg_rtol=1e-8) as eng:      # AUTO: PCG first
