@@ -18,6 +18,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sfmba.h"
@@ -278,6 +279,18 @@ struct sfmba_handle {
 namespace {
 
 using H = sfmba_handle;
+
+// Phase times of sfmba_set_problem on stderr when SFMBA_TRACE_SETUP is set.
+struct SetupTrace {
+    bool on = getenv("SFMBA_TRACE_SETUP") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "  setup %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 void refresh_dev(H* h) {
     Dev& d = h->dev;
@@ -794,6 +807,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
                            const std::vector<int64_t>& pre, const std::vector<int>& pt_ptr,
                            const std::vector<int>& pm_cam, const std::vector<int>& pm2cm) {
     const int n_cam = (int)h->n_cam, np = h->n_pts, no = h->n_obs;
+    SetupTrace tr;
     int mode = h->opt.schur_mode;
     if (const char* e = getenv("SFMBA_SCHUR_MODE")) mode = atoi(e);
     int lin = h->opt.linear_solver;
@@ -822,6 +836,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     if (mode == 0 && (n_pairs > 24 * (int64_t)std::max(no, 1) || n_pairs > 1500000000LL)) return;
     if (n_pairs > 2000000000LL) fail(SFMBA_ERR_INVALID_ARGUMENT, "explicit Schur complement: too many observation pairs");
 
+    tr.lap("schur: count pairs");
     // distinct camera pairs over all points of all ranks
     KeySet keys;
     auto key_of = [](int r, int c) { return ((uint64_t)(uint32_t)r << 32) | (uint32_t)c; };
@@ -843,6 +858,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
                     if (ca != cb) keys.insert(key_of(std::min(ca, cb), std::max(ca, cb)));
                 }
     }
+    tr.lap("schur: camera-pair set");
     std::vector<uint64_t> ukeys;
     ukeys.reserve(keys.count + n_cam);
     for (uint64_t k : keys.tab) if (k != KeySet::kEmpty) ukeys.push_back(k);
@@ -858,30 +874,80 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         const int* e = uc.data() + urow_ptr[r + 1];
         return (int)(std::lower_bound(b, e, c) - uc.data());
     };
-    // count, then fill, the pair list of each upper block (points in increasing order)
+    tr.lap("schur: sort block keys");
+    // Count, then fill, the pair list of each upper block (points in increasing order), on several
+    // host threads: thread t owns a contiguous range of points with an equal share of the pairs,
+    // counts its pairs per block, and after a prefix sum over (block, thread) fills its own
+    // disjoint slice of every block's list, so the result does not depend on the thread count.
+    // Block lookups go through a small per-thread direct-mapped cache (consecutive points mostly
+    // repeat the camera pairs of their neighbours) before the binary search in the block row.
     std::vector<int> bcount((size_t)n_ublk + 1, 0);
-    auto for_each_pair = [&](auto&& emit) {
-        for (int p = 0; p < np; ++p)
+    int nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("SFMBA_THREADS")) nt = std::max(1, atoi(e));
+    if (n_pairs < 200000) nt = 1;
+    std::vector<int> pbeg((size_t)nt + 1, np);
+    {
+        pbeg[0] = 0;
+        int64_t acc = 0;
+        int t = 1;
+        for (int p = 0; p < np && t < nt; ++p) {
+            const int64_t k = pt_ptr[p + 1] - pt_ptr[p];
+            acc += k * (k + 1) / 2;
+            if (acc * nt >= (int64_t)t * n_pairs) pbeg[t++] = p + 1;
+        }
+    }
+    struct BlkCache {
+        std::vector<uint64_t> key; std::vector<int> val;
+        BlkCache() : key(4096, ~0ull), val(4096, 0) {}
+    };
+    auto for_each_pair = [&](int p0, int p1, BlkCache& bc, auto&& emit) {
+        auto blk = [&](int r, int c) {
+            const uint64_t k = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+            const size_t slot = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 52);
+            if (bc.key[slot] != k) { bc.key[slot] = k; bc.val[slot] = find_blk(r, c); }
+            return bc.val[slot];
+        };
+        for (int p = p0; p < p1; ++p)
             for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a) {
                 const int ca = pm_cam[a];
-                emit(find_blk(ca, ca), a, a, p);
+                emit(blk(ca, ca), a, a, p);
                 for (int b = a + 1; b < pt_ptr[p + 1]; ++b) {
                     const int cb = pm_cam[b];
-                    if (ca == cb) { const int u = find_blk(ca, ca); emit(u, a, b, p); emit(u, b, a, p); }
-                    else if (ca < cb) emit(find_blk(ca, cb), a, b, p);
-                    else emit(find_blk(cb, ca), b, a, p);
+                    if (ca == cb) { const int u = blk(ca, ca); emit(u, a, b, p); emit(u, b, a, p); }
+                    else if (ca < cb) emit(blk(ca, cb), a, b, p);
+                    else emit(blk(cb, ca), b, a, p);
                 }
             }
     };
-    for_each_pair([&](int u, int, int, int) { bcount[u + 1]++; });
-    for (int u = 0; u < n_ublk; ++u) bcount[u + 1] += bcount[u];
-    std::vector<int> pa((size_t)n_pairs), pb((size_t)n_pairs), pp((size_t)n_pairs);
-    {
-        std::vector<int> bf(bcount.begin(), bcount.end() - 1);
-        for_each_pair([&](int u, int a, int b, int p) { const int k = bf[u]++; pa[k] = a; pb[k] = b; pp[k] = p; });
+    std::vector<std::vector<int>> tcount((size_t)nt);
+    auto run_threads = [&](auto&& body) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+        body(0);
+        for (auto& x : th) x.join();
+    };
+    run_threads([&](int t) {
+        BlkCache bc;
+        std::vector<int>& cnt = tcount[t];
+        cnt.assign((size_t)n_ublk, 0);
+        for_each_pair(pbeg[t], pbeg[t + 1], bc, [&](int u, int, int, int) { cnt[u]++; });
+    });
+    for (int u = 0; u < n_ublk; ++u) {
+        int tot = 0;
+        for (int t = 0; t < nt; ++t) { const int c = tcount[t][u]; tcount[t][u] = tot; tot += c; }   // offset inside the block
+        bcount[u + 1] = bcount[u] + tot;
     }
-    // the pair kernel reads the camera-major seed arrays
-    for (int64_t k = 0; k < n_pairs; ++k) { pa[k] = pm2cm[pa[k]]; pb[k] = pm2cm[pb[k]]; }
+    std::vector<int> pa((size_t)n_pairs), pb((size_t)n_pairs), pp((size_t)n_pairs);
+    run_threads([&](int t) {
+        BlkCache bc;
+        std::vector<int>& off = tcount[t];
+        for_each_pair(pbeg[t], pbeg[t + 1], bc, [&](int u, int a, int b, int p) {
+            const int k = bcount[u] + off[u]++;
+            pa[k] = pm2cm[a]; pb[k] = pm2cm[b]; pp[k] = p;
+        });
+    });
+    // (pa / pb are positions in the camera-major order: the pair kernel reads those seed arrays)
+    tr.lap("schur: pair lists");
     // pair chunks
     int pchunk = 512;
     if (const char* e = getenv("SFMBA_PAIR_CHUNK")) { int v = atoi(e); if (v >= 64) pchunk = v; }
@@ -908,6 +974,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
             else { upos_t[u] = rf[c]++; bsr_col[upos_t[u]] = r; }
         }
     }
+    tr.lap("schur: chunks + block-CSR");
     hipStream_t st = h->stream;
     h->ublk_r.upload(ur, st); h->ublk_c.upload(uc, st); h->ublk_chunk_ptr.upload(ublk_chunk_ptr, st);
     h->ublk_pos.upload(upos, st); h->ublk_pos_t.upload(upos_t, st);
@@ -923,6 +990,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->Sfull.alloc((size_t)nnzb * 36);
     h->Bsum.zero(st); h->Sfull.zero(st);
     HIP_TRY(hipStreamSynchronize(st));
+    tr.lap("schur: upload");
     h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
     h->explicit_schur = true;
     // single-launch PCG: one workgroup per compute unit at most, every workgroup co-resident
@@ -975,6 +1043,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes exceed 32-bit indexing");
     HIP_TRY(hipSetDevice(h->device));
     h->has_problem = false;
+    SetupTrace tr;
     for (int64_t i = 0; i < n_obs; ++i) {
         if (cam_idx[i] < 0 || cam_idx[i] >= n_cam)
             fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)cam_idx[i], (long long)n_cam);
@@ -1039,6 +1108,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         pm_orig[j] = (int)i;
         pm_uv[j] = make_double2(points_2d[2 * i], points_2d[2 * i + 1]);
     }
+    tr.lap("validate + point-major sort");
     // camera-major order (stable counting sort of the point-major list by camera)
     std::vector<int> cam_ptr((size_t)n_cam + 1, 0);
     for (int j = 0; j < no; ++j) cam_ptr[pm_cam[j] + 1]++;
@@ -1065,6 +1135,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->nb_cam = (int)((n_cam + kBlock - 1) / kBlock);
     if ((np + kBlock - 1) / kBlock > kMaxScalBlocks) fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many points for one GPU");
 
+    tr.lap("camera-major sort + chunks");
     hipStream_t st = h->stream;
     h->pt_ptr.upload(pt_ptr, st); h->pm_cam.upload(pm_cam, st); h->pm_pt.upload(pm_pt, st);
     h->pm_orig.upload(pm_orig, st); h->pm_uv.upload(pm_uv, st);
@@ -1102,7 +1173,9 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         h->dot_off = std::max(h->nb_cam, pcg_spmv_blocks(t));       // p'q partials, then r'z partials
         h->pcg.alloc(2); h->dot_part.alloc((size_t)h->dot_off + pcg_update_blocks(t));
     }
+    tr.lap("uploads + allocations");
     build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm2cm);
+    tr.lap("schur structure (total)");
     if (h->explicit_schur) { h->pm_seed.release(); h->pm_rv.release(); }     // only the matrix-free product reads them
     else { h->pm_seed.alloc((size_t)no); h->pm_rv.alloc((size_t)no); }
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
@@ -1110,6 +1183,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * 36));
     HIP_TRY(hipStreamSynchronize(st));
     do_set_params(h, camera_params, points_3d);
+    tr.lap("parameters");
     h->has_problem = true;
 }
 
