@@ -77,8 +77,9 @@ typedef struct sfmba_options {
     int32_t rank;
     int32_t nranks;
     /* PCG on the explicit reduced matrix: 0 = choose (single launch when the device supports
-     * cooperative launches), 1 = two launches per iteration, 2 = the whole solve in one
-     * cooperative launch (falls back to 1 per solve on a breakdown of its recurrence). */
+     * cooperative launches and can give every camera row a wavefront of its own), 1 = two
+     * launches per iteration, 2 = the whole solve in one cooperative launch (falls back to 1 per
+     * solve on a breakdown of its recurrence). */
     int32_t pcg_mode;
     int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
 } sfmba_options;
