@@ -419,15 +419,17 @@ void phase_linearize(H* h) {
 // mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
     if (h->explicit_schur) {
-        double* bpart = h->Bsum.p + (size_t)h->n_ublk * 36;      // sum W Vinv g_p, behind the blocks
+        // per camera, behind the blocks: T_c = sum W Vinv W' (its own observations: the diagonal
+        // block's share) and sum W Vinv g_p (the point part of the right-hand side)
+        double* tpart = h->Bsum.p + (size_t)h->n_ublk * 36;
         {
             Scope t(h, F_DAMP);
             launch_damp_pm(h->dev, lambda, h->stream);
         }
         {
             Scope t(h, F_DAMP);
-            launch_spmv_cm(h->dev, h->s0.p, nullptr, h->stream);         // sum W Vinv g_p
-            launch_chunk_reduce(h->dev, 6, bpart, h->stream);
+            launch_sdiag_cm(h->dev, h->stream);
+            launch_chunk_reduce(h->dev, 27, tpart, h->stream);
         }
         {
             Scope t(h, F_SCHUR);
@@ -437,10 +439,10 @@ void phase_damp(H* h, double lambda) {
             }
             launch_block_reduce(h->dev, h->stream);
         }
-        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36 + (size_t)h->n_cam * 6);
+        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36 + (size_t)h->n_cam * 27);
         {
             Scope t(h, F_SCHUR);
-            launch_schur_finish(h->dev, lambda, bpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
+            launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
         }
     } else {
         Scope t(h, F_DAMP);
@@ -825,9 +827,9 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     if (mode == 1) return;
     // pairs of this partition
     int64_t n_pairs = 0;
-    for (int p = 0; p < np; ++p) {
-        const int64_t k = pt_ptr[p + 1] - pt_ptr[p];
-        n_pairs += k * (k + 1) / 2;
+    for (int p = 0; p < np; ++p) {            // (an observation with itself is not a pair: the diagonal
+        const int64_t k = pt_ptr[p + 1] - pt_ptr[p];      // blocks come from a camera-major pass)
+        n_pairs += k * (k - 1) / 2;
     }
     for (int p = 0; p < np; ++p)              // same-camera duplicates inside a point add one entry each
         for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a)
@@ -892,7 +894,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         int t = 1;
         for (int p = 0; p < np && t < nt; ++p) {
             const int64_t k = pt_ptr[p + 1] - pt_ptr[p];
-            acc += k * (k + 1) / 2;
+            acc += k * (k - 1) / 2;
             if (acc * nt >= (int64_t)t * n_pairs) pbeg[t++] = p + 1;
         }
     }
@@ -910,7 +912,6 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         for (int p = p0; p < p1; ++p)
             for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a) {
                 const int ca = pm_cam[a];
-                emit(blk(ca, ca), a, a, p);
                 for (int b = a + 1; b < pt_ptr[p + 1]; ++b) {
                     const int cb = pm_cam[b];
                     if (ca == cb) { const int u = blk(ca, ca); emit(u, a, b, p); emit(u, b, a, p); }
@@ -986,7 +987,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
     h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);
     h->pair_part.alloc((size_t)std::max<size_t>(pchunk_blk.size(), 1) * 36);
-    h->Bsum.alloc((size_t)n_ublk * 36 + (size_t)n_cam * 6);      // + the reduced right-hand side part, one collective
+    h->Bsum.alloc((size_t)n_ublk * 36 + (size_t)n_cam * 27);     // + the per-camera sums T_c, one collective
     h->Sfull.alloc((size_t)nnzb * 36);
     h->Bsum.zero(st); h->Sfull.zero(st);
     HIP_TRY(hipStreamSynchronize(st));

@@ -164,7 +164,7 @@ int bsr_blocks(const Dev& d);
 void launch_schur_pairs(const Dev& d, hipStream_t st);
 void launch_block_reduce(const Dev& d, hipStream_t st);
 // full matrix, preconditioner, right-hand side; with `scaled` also F, bhat, Shat of the single-launch PCG
-void launch_schur_finish(const Dev& d, double lambda, const double* bpart, const FusedPcg* scaled, hipStream_t st);
+void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)

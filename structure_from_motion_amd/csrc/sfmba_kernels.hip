@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
 }
 
 // Camera-major: chunk partials of T_c = sum W Vinv W' (21 packed upper) and sum W s0 (6),
-// W = Jc' Jp (6x3).
+// W = Jc' Jp (6x3), formed as Jc' (Jp Vinv Jp') Jc without the 6x3 intermediates.
 __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
     __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
@@ -233,25 +233,29 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
         double jc[12], a[3], b[3];
         jac_cam(s, d.K, jc);
         jac_pt(s, d.K, cam.q, a, b);
-        // W (6x3) and M = W Vinv (6x3)
-        double W[6][3], M[6][3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) W[i][kk] = jc[i] * a[kk] + jc[6 + i] * b[kk];
-            M[i][0] = W[i][0] * v01.x + W[i][1] * v01.y + W[i][2] * v23.x;
-            M[i][1] = W[i][0] * v01.y + W[i][1] * v23.y + W[i][2] * v45.x;
-            M[i][2] = W[i][0] * v23.x + W[i][1] * v45.x + W[i][2] * v45.y;
-        }
+        // M = Jp Vinv Jp' (2x2 symmetric), then Jc' M Jc (upper triangle)
+        const double ta0 = v01.x * a[0] + v01.y * a[1] + v23.x * a[2];
+        const double ta1 = v01.y * a[0] + v23.y * a[1] + v45.x * a[2];
+        const double ta2 = v23.x * a[0] + v45.x * a[1] + v45.y * a[2];
+        const double tb0 = v01.x * b[0] + v01.y * b[1] + v23.x * b[2];
+        const double tb1 = v01.y * b[0] + v23.y * b[1] + v45.x * b[2];
+        const double tb2 = v23.x * b[0] + v45.x * b[1] + v45.y * b[2];
+        const double m00 = a[0] * ta0 + a[1] * ta1 + a[2] * ta2;
+        const double m01 = a[0] * tb0 + a[1] * tb1 + a[2] * tb2;
+        const double m11 = b[0] * tb0 + b[1] * tb1 + b[2] * tb2;
         int n = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i) {
+            const double l0 = jc[i] * m00 + jc[6 + i] * m01;
+            const double l1 = jc[i] * m01 + jc[6 + i] * m11;
 #pragma unroll
-            for (int j = i; j < 6; ++j)
-                acc[n++] += M[i][0] * W[j][0] + M[i][1] * W[j][1] + M[i][2] * W[j][2];
-        // W * (Vinv g_p) : the right-hand-side contribution
+            for (int j = i; j < 6; ++j) acc[n++] += l0 * jc[j] + l1 * jc[6 + j];
+        }
+        // Jc' (Jp (Vinv g_p)): the right-hand-side contribution
+        const double w0 = a[0] * s0.x + a[1] * s0.y + a[2] * s0.z;
+        const double w1 = b[0] * s0.x + b[1] * s0.y + b[2] * s0.z;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += W[i][0] * s0.x + W[i][1] * s0.y + W[i][2] * s0.z;
+        for (int i = 0; i < 6; ++i) acc[21 + i] += jc[i] * w0 + jc[6 + i] * w1;
     }
     double tot[2];
     wave_sum_lds<27, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);

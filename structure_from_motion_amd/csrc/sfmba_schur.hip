@@ -1,8 +1,9 @@
 // Explicit block-sparse Schur complement of libsfmba (gfx950, fp64).
 //
 // S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p' has a 6x6 block for every pair of
-// cameras that share a point.  The host lists, per upper block (r <= c), the pairs of
-// observations (a, b) of one point with camera(a) = r and camera(b) = c, sorted by block and cut
+// cameras that share a point.  The host lists, per upper block (r <= c), the pairs of distinct
+// observations (a, b) of one point with camera(a) = r and camera(b) = c (an observation paired
+// with itself belongs to the diagonal block and is summed by the camera-major pass k_sdiag_cm), sorted by block and cut
 // into chunks; one wavefront owns one chunk, both cameras are wave-uniform, every lane forms
 //     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (6x2 . 2x2 . 2x6)
 // for its pairs from the stored camera-major seeds, sums in registers, and the wavefront reduces the 36 sums
@@ -97,15 +98,17 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d) {
 
 // Finishing passes over the (all-ranks) upper sums B: S_rc = -B, S_cr = -B', S_cc = U*_c - B_cc.
 //
-// k_finish_diag, one thread per camera: the diagonal block of the full block-CSR matrix, its
+// k_finish_diag, one thread per camera: the diagonal block of the full block-CSR matrix
+// (U*_c - T_c - B_cc with T_c from the camera-major pass k_sdiag_cm), its
 // Cholesky factor, the inverse (block-Jacobi preconditioner), the reduced right-hand side
 // rhs = -g_c + sum W Vinv g_p and, for the single-launch PCG, the scaling F = L^-1, bhat = F rhs
 // and the scaled diagonal block F S_cc F'.
-__global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, const double* __restrict__ bpart, FusedPcg f) {
+__global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f) {
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= d.n_cam) return;
     const double* U = d.UG + 27 * (size_t)c;
-    const double* B = d.Bsum + 36 * (size_t)d.ublk_diag[c];
+    const double* T = tpart + 27 * (size_t)c;          // packed upper sum W Vinv W' | sum W Vinv g_p
+    const double* B = d.Bsum + 36 * (size_t)d.ublk_diag[c];   // pairs of two observations of one point in this camera
     double S[6][6], A[6][6], Li[6][6], Ai[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, co
             const int a = i < j ? i : j, b = i < j ? j : i;
             double uv = U[upidx(6, a, b)];
             if (i == j) uv += lambda * fmin(fmax(uv, 1e-6), 1e32);
-            S[i][j] = uv - B[6 * i + j];
+            S[i][j] = uv - T[upidx(6, a, b)] - B[6 * i + j];
             Li[i][j] = 0.0;
         }
     double* So = d.Sfull + 36 * (size_t)d.bsr_diag[c];
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, co
     double r[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        r[i] = -g[i] + bpart[6 * (size_t)c + i];
+        r[i] = -g[i] + T[21 + i];
         d.rhs[6 * (size_t)c + i] = r[i];
     }
     if (f.F == nullptr) return;
     double* Fo = const_cast<double*>(f.F) + 36 * (size_t)c;
     double* bo = const_cast<double*>(f.bhat) + 6 * (size_t)c;
-    double T[6][6];                 // F S
+    double FS[6][6];                // F S
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = 0.0;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, co
             double t = 0.0;
 #pragma unroll
             for (int k = 0; k <= i; ++k) t += Li[i][k] * S[k][j];
-            T[i][j] = t;
+            FS[i][j] = t;
         }
         bo[i] = v;
     }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, co
         for (int j = 0; j < 6; ++j) {
             double v = 0.0;
 #pragma unroll
-            for (int l = 0; l <= j; ++l) v += T[i][l] * Li[j][l];
+            for (int l = 0; l <= j; ++l) v += FS[i][l] * Li[j][l];
             Ho[6 * i + j] = v;
         }
 }
@@ -254,10 +257,10 @@ void launch_block_reduce(const Dev& d, hipStream_t st) {
     if (d.n_ublk > 0)
         hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d);
 }
-void launch_schur_finish(const Dev& d, double lambda, const double* bpart, const FusedPcg* scaled, hipStream_t st) {
+void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st) {
     FusedPcg f{};
     if (scaled) f = *scaled;
-    hipLaunchKernelGGL(k_finish_diag, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, bpart, f);
+    hipLaunchKernelGGL(k_finish_diag, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, tpart, f);
     if (d.n_ublk > 0)
         hipLaunchKernelGGL(k_finish_offdiag, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d, f);
 }
