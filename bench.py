@@ -210,7 +210,7 @@ def main():
                        "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU",
                        "linear_solver": {1: "pcg", 2: "dense-cholesky"}[last.linear_solver],
                        "schur_mode": {1: "implicit", 2: "explicit"}[last.schur_mode],
-                       "pcg": "single cooperative launch" if last.pcg_single_launch else "launch per iteration"},
+                       "pcg": "single launch" if last.pcg_single_launch else "launch per iteration"},
             "lm_iters_per_sec": iters / elapsed,
             "lm_iterations_per_solve": iters / args.steps,
             "pcg_iterations_per_solve": sum(s.pcg_iterations for s in stats) / args.steps,

@@ -76,10 +76,10 @@ typedef struct sfmba_options {
      * (equal observation counts).  nranks <= 1 means the whole problem. */
     int32_t rank;
     int32_t nranks;
-    /* PCG on the explicit reduced matrix: 0 = choose (single launch when the device supports
-     * cooperative launches and can give every camera row a wavefront of its own), 1 = two
-     * launches per iteration, 2 = the whole solve in one cooperative launch (falls back to 1 per
-     * solve on a breakdown of its recurrence). */
+    /* PCG on the explicit reduced matrix: 0 = choose (single launch when the device can give
+     * every camera row a wavefront of its own), 1 = two launches per iteration, 2 = the whole
+     * solve in one launch whose workgroups synchronise through memory (falls back to 1 per solve
+     * on a breakdown of its recurrence or when its workgroups do not all become resident). */
     int32_t pcg_mode;
     int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
 } sfmba_options;

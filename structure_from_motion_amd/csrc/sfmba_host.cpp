@@ -180,6 +180,7 @@ struct LocalGroup {
     long generation = 0;
     int next_rank_check = 0;
     std::vector<double*> bufs;
+    std::vector<size_t> counts;
     std::vector<int> devices;
     bool failed = false;
     void barrier() {
@@ -236,7 +237,7 @@ struct sfmba_handle {
     DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
     DBuf<double> pair_part, Bsum, Sfull;
     // single-launch PCG on the scaled system
-    bool fused_pcg = false;
+    bool fused_pcg = false, fused_armed = false, fused_cooperative = false, fused_refused = false;
     int fused_blocks = 0;
     int64_t fused_solves = 0, fused_fallbacks = 0;
     DBuf<double> Shat, Fscale, bhat, fvec;    // fvec: generation records, p, xh
@@ -359,9 +360,12 @@ void allreduce(H* h, double* buf, size_t count) {
         const int rk = h->opt.rank;
         HIP_TRY(hipStreamSynchronize(h->stream));
         g->bufs[rk] = buf;
+        g->counts[rk] = count;
         g->barrier();
         if (rk == 0) {                       // fixed rank order: bitwise reproducible
             hipError_t e = hipSuccess;
+            for (int r = 1; r < g->n; ++r)   // ranks out of step: refuse before touching memory
+                if (g->counts[r] != count) e = hipErrorInvalidValue;
             for (int r = 1; r < g->n && e == hipSuccess; ++r) {
                 launch_vec_add(buf, g->bufs[r], count, h->stream);
                 e = hipGetLastError();
@@ -443,6 +447,7 @@ void phase_damp(H* h, double lambda) {
         {
             Scope t(h, F_SCHUR);
             launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
+            h->fused_armed = h->fused_pcg;
         }
     } else {
         Scope t(h, F_DAMP);
@@ -478,26 +483,43 @@ PcgState phase_pcg(H* h, double lambda) {
     const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
     const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     if (h->explicit_schur && h->fused_pcg) {
-        // the whole solve in one cooperative launch; a breakdown of the single-reduction
+        // the whole solve in one launch; a breakdown of the single-reduction
         // recurrence or a barrier timeout falls through to the launch-per-iteration solver
         FusedPcg& f = h->fused;
         f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = max_iter;
-        hipError_t e;
-        {
+        hipError_t e = hipErrorNotSupported;
+        if (!h->fused_refused) {
             Scope t(h, F_BSR);
-            e = launch_pcg_fused(f, h->fused_blocks, h->stream);
+            // (plain launch: grids of several handles that meet on one GPU can keep each other from
+            // becoming resident; the admission timeout then sends those solves to the fallback)
+            e = launch_pcg_fused(f, h->fused_armed, h->fused_cooperative, h->stream);
+            h->fused_armed = false;
         }
+        PcgState st{};
+        st.pad = 4;                             // launch refused
         if (e == hipSuccess) {
             HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            const PcgState st = h->pcg_host[0];
-            if (h->trace_pcg)
-                fprintf(stderr, "pcg single launch: %d iterations, %.2f us in kernel, flag %d\n", st.iter, st.ticks * 0.01, st.pad);
-            if (st.pad == 0) { h->fused_solves++; return st; }
-        } else {
+            st = h->pcg_host[0];
+        } else if (!h->fused_refused) {
+            if (h->trace_pcg) fprintf(stderr, "pcg single launch refused: %s\n", hipGetErrorString(e));
             (void)hipGetLastError();
-            h->fused_pcg = false;               // cooperative launch not available: do not try again
+            h->fused_refused = true;            // no further launches; with a communicator this rank
+            if (!h->has_comm()) h->fused_pcg = false;   // still takes part in the ranks' agreement below
         }
+        if (h->has_comm()) {
+            // every rank solves the same replicated system, but a timeout or a refused launch can
+            // hit one of them: either all keep the single-launch result or all redo the solve
+            double flag = st.pad != 0 ? 1.0 : 0.0;
+            HIP_TRY(hipMemcpyAsync(h->tmp_b.p, &flag, sizeof(double), hipMemcpyHostToDevice, h->stream));
+            allreduce(h, h->tmp_b.p, 1);
+            HIP_TRY(hipMemcpyAsync(&flag, h->tmp_b.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (flag != 0.0 && st.pad == 0) st.pad = 3;
+        }
+        if (h->trace_pcg && e == hipSuccess)
+            fprintf(stderr, "pcg single launch: %d iterations, %.2f us in kernel, flag %d\n", st.iter, st.ticks * 0.01, st.pad);
+        if (st.pad == 0) { h->fused_solves++; return st; }
         h->fused_fallbacks++;
     }
     {
@@ -1024,8 +1046,12 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
             f.dots = h->fdots.p;
             h->trace_pcg = getenv("SFMBA_PCG_TRACE") != nullptr;
             f.timeout_ticks = 20000000LL;         // 0.2 s of the 100 MHz wall clock
+            f.admit_ticks = 200000LL;             // 2 ms
+            f.blocks = blocks;
+            h->fused_cooperative = getenv("SFMBA_PCG_COOPERATIVE") != nullptr && atoi(getenv("SFMBA_PCG_COOPERATIVE")) != 0;
             h->fused_blocks = blocks;
             h->fused_pcg = true;
+            h->fused_refused = false;
         }
     }
     if (want_dense) {
@@ -1554,6 +1580,7 @@ int sfmba_local_group_create(int32_t nranks, void** out) {
     if (!g) return SFMBA_ERR_INVALID_ARGUMENT;
     g->n = nranks;
     g->bufs.assign(nranks, nullptr);
+    g->counts.assign(nranks, 0);
     g->devices.assign(nranks, -1);
     *out = g;
     return SFMBA_OK;

@@ -56,8 +56,12 @@ struct FusedPcg {
     PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout
     double tol2;
     int max_iter;
-    long long timeout_ticks;  // of the 100 MHz wall clock
+    long long timeout_ticks;  // of the 100 MHz wall clock: any later poll
+    long long admit_ticks;    // the first poll (all workgroups resident and started)
+    int blocks;               // workgroups of the launch
 };
+constexpr int kPcgSlots = 4;      // rotating generation slots of the single-launch PCG
+constexpr int kPcgVecRec = 18;    // r[6] w[6] s[6] of one camera and generation
 
 // Everything a kernel needs, passed by value.  "pm" arrays are in point-major observation
 // order (observations of one point contiguous), "cm" arrays in camera-major order.
@@ -145,12 +149,14 @@ void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st);            // e
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);                 // implicit mode: direction only
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);    // implicit mode: q = U* p - qS
 void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
-// whole PCG solve in one cooperative launch (explicit mode); returns the launch error
+// whole PCG solve in one launch (explicit mode); returns the launch error
 int pcg_fused_max_blocks(int device);
 int pcg_fused_rows_per_block();
 size_t pcg_fused_record_words(int blocks);
 size_t pcg_fused_vector_words(int n_cam);
-hipError_t launch_pcg_fused(const FusedPcg& f, int blocks, hipStream_t st);
+// `armed`: the records already hold the sentinel (k_finish_diag did it); `cooperative`: ask the
+// runtime for guaranteed co-residency (costs tens of microseconds per launch)
+hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, bool cooperative, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);

@@ -239,13 +239,16 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_
 // write-back or invalidation, and the matrix stays in registers (or L2).  Workgroup-internal
 // barriers order LDS traffic only and never wait for those stores.
 //
-// The grid must be co-resident (cooperative launch).  A poll that exceeds timeout_ticks clears
-// the abort word, which every polling wavefront checks, so the grid always drains.
+// The grid must be co-resident: one workgroup per compute unit at most, launched either with the
+// runtime's cooperative guarantee or plainly (an otherwise idle device schedules all of them at
+// once).  A poll that exceeds its time limit - admit_ticks for the first one, which waits for every
+// workgroup to show up, timeout_ticks afterwards - clears the abort word, which every polling
+// wavefront checks, so the grid always drains; the caller then solves launch by launch.
 constexpr int kFusedThreads = 512;
 constexpr int kFusedWaves = kFusedThreads / 64;
-constexpr int kVecRec = 18;                       // r[6] w[6] s[6] of one camera and generation
+constexpr int kVecRec = kPcgVecRec;
 constexpr unsigned long long kSentinel = ~0ull;
-constexpr int kSlots = 4;                         // rotating generation slots
+constexpr int kSlots = kPcgSlots;
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for
 // outstanding global stores to be acknowledged.
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
     double* tile = tiles[w];
     Poller poll;
     poll.abort_word = drec + 2 * kSlots * (size_t)G;
-    poll.deadline = t_start + a.timeout_ticks;
+    poll.deadline = t_start + a.admit_ticks;          // until every workgroup has shown up
     const size_t gen_stride = (size_t)a.n_cam * kVecRec;
     if (tid == 0) fail_lds = 0;
 
@@ -517,6 +520,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
         if (!okw && lane == 0) fail_lds = 1;
         block_barrier();
         if (fail_lds) { flag = 2; break; }
+        poll.deadline = t_start + a.timeout_ticks;
         double del = 0.0;
         gam = 0.0;
 #pragma unroll
@@ -653,15 +657,23 @@ int pcg_fused_rows_per_block() { return kFusedWaves; }
 size_t pcg_fused_record_words(int blocks) { return 2 * kSlots * (size_t)blocks + 1; }
 size_t pcg_fused_vector_words(int n_cam) { return kSlots * (size_t)n_cam * kVecRec; }
 
-// Arms every record (all bits set) and the abort word, then launches the solve.
-hipError_t launch_pcg_fused(const FusedPcg& f, int blocks, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(f.dots, 0xFF, pcg_fused_record_words(blocks) * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(f.vec, 0xFF, pcg_fused_vector_words(f.n_cam) * sizeof(double), st);
-    if (e != hipSuccess) return e;
+// Arms every record (all bits set) and the abort word unless that has been done, then launches
+// the solve.  Without the cooperative guarantee the kernel relies on its admission timeout: a
+// grid that does not become fully resident within admit_ticks aborts and the caller falls back.
+hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, bool cooperative, hipStream_t st) {
+    if (!armed) {
+        hipError_t e = hipMemsetAsync(f.dots, 0xFF, pcg_fused_record_words(f.blocks) * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(f.vec, 0xFF, pcg_fused_vector_words(f.n_cam) * sizeof(double), st);
+        if (e != hipSuccess) return e;
+    }
     FusedPcg arg = f;
-    void* params[] = {&arg};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_pcg_fused), dim3(blocks), dim3(kFusedThreads), params, 0, st);
+    if (cooperative) {
+        void* params[] = {&arg};
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_pcg_fused), dim3(f.blocks), dim3(kFusedThreads), params, 0, st);
+    }
+    hipLaunchKernelGGL(k_pcg_fused, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    return hipGetLastError();
 }
 
 void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {

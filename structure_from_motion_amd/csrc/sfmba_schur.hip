@@ -101,10 +101,18 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d) {
 // k_finish_diag, one thread per camera: the diagonal block of the full block-CSR matrix
 // (U*_c - T_c - B_cc with T_c from the camera-major pass k_sdiag_cm), its
 // Cholesky factor, the inverse (block-Jacobi preconditioner), the reduced right-hand side
-// rhs = -g_c + sum W Vinv g_p and, for the single-launch PCG, the scaling F = L^-1, bhat = F rhs
-// and the scaled diagonal block F S_cc F'.
+// rhs = -g_c + sum W Vinv g_p and, for the single-launch PCG, the scaling F = L^-1, bhat = F rhs,
+// the scaled diagonal block F S_cc F' and the armed (all bits set) exchange buffers.
 __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f) {
     const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (f.F != nullptr) {
+        // arm the exchange buffers of the single-launch PCG: every word all bits set
+        unsigned long long* vw = reinterpret_cast<unsigned long long*>(f.vec);
+        unsigned long long* dw = reinterpret_cast<unsigned long long*>(f.dots);
+        const size_t nv = (size_t)kPcgSlots * d.n_cam * kPcgVecRec, nd = 2 * (size_t)kPcgSlots * f.blocks + 1;
+        for (size_t i = c; i < nv; i += (size_t)gridDim.x * kBlock) vw[i] = ~0ull;
+        for (size_t i = c; i < nd; i += (size_t)gridDim.x * kBlock) dw[i] = ~0ull;
+    }
     if (c >= d.n_cam) return;
     const double* U = d.UG + 27 * (size_t)c;
     const double* T = tpart + 27 * (size_t)c;          // packed upper sum W Vinv W' | sum W Vinv g_p

@@ -17,7 +17,7 @@ from structure_from_motion_amd.engine import Engine, EngineError
 pytestmark = pytest.mark.gpu
 
 # (linear_solver, schur_mode, pcg_mode): PCG on the implicit operator, PCG on the explicit
-# block-sparse matrix as one cooperative launch and as two launches per iteration, dense MFMA
+# block-sparse matrix as one launch and as two launches per iteration, dense MFMA
 # Cholesky on the explicit matrix
 SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
            "pcg-explicit": dict(linear_solver=1, schur_mode=2, pcg_mode=2),
