@@ -204,6 +204,7 @@ struct sfmba_handle {
     bool has_problem = false;
     bool linearized = false;
     double lin_lambda = 0.0;
+    double damped_lambda = -1.0;   // damping for which Vinv and s0 are current
 
     // global shape and this partition
     int64_t n_cam = 0, n_pts_all = 0, n_obs_all = 0;
@@ -399,10 +400,13 @@ void reduce_scalars(H* h, int first, int count) {
 // Linearise at the current estimate: seeds, residuals, V_p, g_p, U_c, g_c.  Leaves the cost sum
 // in scalars[SLOT_COST] (this partition's part), max|g_p| in scalars[SLOT_GMAX_PT] and max|g_c|
 // in scalars[SLOT_GMAX_CAM].  (Running the two halves on two streams was measured: no gain.)
-void phase_linearize(H* h) {
+// `lambda` is the damping of the step that will follow (0 = not known): the points are then damped
+// in the same pass and phase_damp(lambda) finds that done.
+void phase_linearize(H* h, double lambda = 0.0) {
     Scope t(h, F_LIN);
     refresh_dev(h);
-    launch_lin_pm(h->dev, !h->explicit_schur, h->stream);
+    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream);
+    h->damped_lambda = lambda > 0.0 ? lambda : -1.0;
     launch_lin_cm(h->dev, h->stream);
     launch_chunk_reduce(h->dev, 27, h->UG.p, h->stream);
     if (h->has_comm()) {
@@ -426,7 +430,7 @@ void phase_damp(H* h, double lambda) {
         // per camera, behind the blocks: T_c = sum W Vinv W' (its own observations: the diagonal
         // block's share) and sum W Vinv g_p (the point part of the right-hand side)
         double* tpart = h->Bsum.p + (size_t)h->n_ublk * 36;
-        {
+        if (h->damped_lambda != lambda) {
             Scope t(h, F_DAMP);
             launch_damp_pm(h->dev, lambda, h->stream);
         }
@@ -451,7 +455,7 @@ void phase_damp(H* h, double lambda) {
         }
     } else {
         Scope t(h, F_DAMP);
-        launch_damp_pm(h->dev, lambda, h->stream);
+        if (h->damped_lambda != lambda) launch_damp_pm(h->dev, lambda, h->stream);
         launch_sdiag_cm(h->dev, h->stream);
         launch_chunk_reduce(h->dev, 27, h->T.p, h->stream);
         allreduce(h, h->T.p, (size_t)h->n_cam * 27);
@@ -459,6 +463,7 @@ void phase_damp(H* h, double lambda) {
     }
     h->linearized = true;
     h->lin_lambda = lambda;
+    h->damped_lambda = lambda;
 }
 
 // qS = sum over observations of W Vinv W' x (this partition's part, then all ranks').
@@ -663,7 +668,7 @@ void do_solve(H* h, sfmba_stats* out) {
     auto t0 = std::chrono::steady_clock::now();
     double sc[SLOT_COUNT];
 
-    phase_linearize(h);
+    phase_linearize(h, lambda);
     st.njev = 1;
     reduce_scalars(h, SLOT_COST, 1);
     double g_norm = read_lin_scalars(h, sc);
@@ -701,7 +706,7 @@ void do_solve(H* h, sfmba_stats* out) {
             lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-15);
             nu = 2.0;
             cost = cost_new;
-            phase_linearize(h);          // also the gradient norm at the new iterate
+            phase_linearize(h, lambda);  // also the gradient norm at the new iterate; damps for the next step
             st.njev++;
             g_norm = read_lin_scalars(h, sc);
             if (talk) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, false);

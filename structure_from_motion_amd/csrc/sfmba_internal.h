@@ -132,7 +132,7 @@ struct Dev {
 // ---- launch wrappers (sfmba_kernels.hip) -------------------------------------------------
 void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);
 void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStream_t st);
-void launch_lin_pm(const Dev& d, bool store_seeds, hipStream_t st);   // seeds are only stored for the matrix-free Schur product
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
 void launch_lin_cm(const Dev& d, hipStream_t st);               // chunk partials (27 values)
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);

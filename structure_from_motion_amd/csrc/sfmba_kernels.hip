@@ -73,11 +73,34 @@ __device__ __forceinline__ Tile wave_tile(const Dev& d) {
     return t;
 }
 
+// Damping of one point: Vinv = (V + lambda * clamp(diag V))^-1 and s0 = Vinv g_p.
+__device__ __forceinline__ void damp_point(const Dev& d, int p, const double* Vin, const double* g, double lambda) {
+    double V[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) V[i] = Vin[i];
+    V[0] += lambda * fmin(fmax(V[0], 1e-6), 1e32);
+    V[3] += lambda * fmin(fmax(V[3], 1e-6), 1e32);
+    V[5] += lambda * fmin(fmax(V[5], 1e-6), 1e32);
+    double inv[6];
+    spd3_inverse(V, inv);
+    double* o = d.Vinv + 6 * (size_t)p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = inv[i];
+    double4 s;
+    s.x = inv[0] * g[0] + inv[1] * g[1] + inv[2] * g[2];
+    s.y = inv[1] * g[0] + inv[3] * g[1] + inv[4] * g[2];
+    s.z = inv[2] * g[0] + inv[4] * g[1] + inv[5] * g[2];
+    s.w = 0.0;
+    d.s0[p] = s;
+}
+
 // Linearisation, point-major half: V_p and g_p per point, cost and gradient maximum; with kStore
 // also the seeds + residuals per observation, which only the matrix-free Schur product reads
 // (every other consumer rebuilds them from X and the camera it gathers anyway).
+// With lambda > 0 the writer lane also damps its point: Vinv = (V + lambda clamp(diag V))^-1 and
+// s0 = Vinv g_p, what k_damp_pm would otherwise read V and g_p back for.
 template <bool kStore>
-__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
+__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
     __shared__ double red[block_reduce_scratch<2>()];
     const int lane = threadIdx.x & 63;
     const Tile t = wave_tile(d);
@@ -126,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d) {
         double* go = d.gp + 4 * (size_t)key;
         go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
         gmax = fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8])));
+        if (lambda > 0.0) damp_point(d, key, acc, acc + 6, lambda);
     }
     static_assert(SLOT_GMAX_PT == SLOT_COST + 1, "slot order");
     const double vals[2] = {cost, gmax};
@@ -189,25 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_reduce(Dev d, int nvals, doubl
 __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
     int p = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (p >= d.n_pts) return;
-    const double* Vi = d.V + 6 * (size_t)p;
-    double V[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) V[i] = Vi[i];
-    V[0] += lambda * fmin(fmax(V[0], 1e-6), 1e32);
-    V[3] += lambda * fmin(fmax(V[3], 1e-6), 1e32);
-    V[5] += lambda * fmin(fmax(V[5], 1e-6), 1e32);
-    double inv[6];
-    spd3_inverse(V, inv);
-    double* o = d.Vinv + 6 * (size_t)p;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = inv[i];
-    const double* g = d.gp + 4 * (size_t)p;
-    double4 s;
-    s.x = inv[0] * g[0] + inv[1] * g[1] + inv[2] * g[2];
-    s.y = inv[1] * g[0] + inv[3] * g[1] + inv[4] * g[2];
-    s.z = inv[2] * g[0] + inv[4] * g[1] + inv[5] * g[2];
-    s.w = 0.0;
-    d.s0[p] = s;
+    damp_point(d, p, d.V + 6 * (size_t)p, d.gp + 4 * (size_t)p, lambda);
 }
 
 // Camera-major: chunk partials of T_c = sum W Vinv W' (21 packed upper) and sum W s0 (6),
@@ -623,11 +629,11 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     if (d.n_obs == 0) return;
     hipLaunchKernelGGL(k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, jc, jp);
 }
-void launch_lin_pm(const Dev& d, bool store_seeds, hipStream_t st) {
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st) {
     const int nb = blocks_wtile(d);
     if (nb > 0) {
-        if (store_seeds) hipLaunchKernelGGL(k_lin_pm<true>, dim3(nb), dim3(kBlock), 0, st, d);
-        else hipLaunchKernelGGL(k_lin_pm<false>, dim3(nb), dim3(kBlock), 0, st, d);
+        if (store_seeds) hipLaunchKernelGGL(k_lin_pm<true>, dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        else hipLaunchKernelGGL(k_lin_pm<false>, dim3(nb), dim3(kBlock), 0, st, d, lambda);
     }
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
 }
