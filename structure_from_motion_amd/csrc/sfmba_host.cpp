@@ -484,14 +484,14 @@ void schur_product(H* h, const double* x, const PcgState* state) {
 }
 
 // Block-Jacobi PCG on S dc = rhs; result in px.  Returns the iteration count.
-PcgState phase_pcg(H* h, double lambda) {
+PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
     const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
     const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
-    if (h->explicit_schur && h->fused_pcg) {
+    if (allow_fused && h->explicit_schur && h->fused_pcg) {
         // the whole solve in one launch; a breakdown of the single-reduction
         // recurrence or a barrier timeout falls through to the launch-per-iteration solver
         FusedPcg& f = h->fused;
-        f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = max_iter;
+        f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = max_iter; f.flag_slot = nullptr;
         hipError_t e = hipErrorNotSupported;
         if (!h->fused_refused) {
             Scope t(h, F_BSR);
@@ -594,12 +594,12 @@ bool phase_dense(H* h) {
 // Camera step of the damped normal equations into px; returns the PCG iteration count (0 = dense).
 // PCG is the default; the dense Cholesky runs when it was asked for, and as the fallback when PCG
 // ran out of iterations on a system small enough to factor (6 n_cameras <= dense_max_dim).
-int phase_linear_solve(H* h, double lambda) {
+int phase_linear_solve(H* h, double lambda, bool allow_fused = true) {
     if (h->use_dense) {
         if (phase_dense(h)) return 0;
         h->dense_fallbacks++;
     }
-    const PcgState st = phase_pcg(h, lambda);
+    const PcgState st = phase_pcg(h, lambda, allow_fused);
     const bool converged = !(st.rz > st.tol2 * st.rz0);
     if (!converged && !h->use_dense && h->dense_allowed && h->explicit_schur) {
         if (h->denseA.n == 0) {
@@ -612,9 +612,38 @@ int phase_linear_solve(H* h, double lambda) {
         h->dense_fallbacks++;
         if (phase_dense(h)) return st.iter;
         // factorisation failed too: keep the PCG iterate (it is a descent direction)
-        (void)phase_pcg(h, lambda);
+        (void)phase_pcg(h, lambda, allow_fused);
     }
     return st.iter;
+}
+
+// Single-launch PCG without waiting for its outcome: its flag goes into a scalar slot that
+// travels (and, with a communicator, is summed over the ranks) with the scalars of the trial step,
+// its state into pinned host memory; both are looked at after the trial step, which saves a host
+// synchronisation and, between ranks, a collective per LM iteration.  Returns false when the solve
+// has to take the synchronous route (other solver, launch refused earlier).
+bool launch_linear_solve_async(H* h) {
+    if (!(h->explicit_schur && h->fused_pcg && !h->fused_refused && !h->use_dense)) return false;
+    const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
+    FusedPcg& f = h->fused;
+    f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
+    f.flag_slot = h->scalars.p + SLOT_PCGFLAG;
+    hipError_t e;
+    {
+        Scope t(h, F_BSR);
+        e = launch_pcg_fused(f, h->fused_armed, h->fused_cooperative, h->stream);
+        h->fused_armed = false;
+    }
+    if (e != hipSuccess) {
+        // refused on this rank: tell the others through the flag, take the synchronous route from now on
+        (void)hipGetLastError();
+        h->fused_refused = true;
+        const double one = 1.0;
+        HIP_TRY(hipMemcpyAsync(h->scalars.p + SLOT_PCGFLAG, &one, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
+    return true;
 }
 
 // Step evaluation: back-substitution, retraction into the trial buffers, trial cost.
@@ -624,7 +653,7 @@ void phase_trial(H* h, double* dp_out) {
         launch_cam_update(h->dev, h->px.p, h->stream);          // the trial cameras first:
         launch_back_pm(h->dev, h->px.p, dp_out, h->stream);     // this pass also evaluates the trial cost
     }
-    reduce_scalars(h, SLOT_MODEL, SLOT_NONFINITE - SLOT_MODEL + 1);
+    reduce_scalars(h, SLOT_MODEL, SLOT_PCGFLAG - SLOT_MODEL + 1);
 }
 
 // Scalars of the linearisation: the slots, and the largest |g_p| over all partitions.
@@ -684,9 +713,34 @@ void do_solve(H* h, sfmba_stats* out) {
     if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
     for (int it = 0; it < max_it && status < 0; ++it) {
         phase_damp(h, lambda);
-        st.pcg_iterations += phase_linear_solve(h, lambda);
+        const bool pending = launch_linear_solve_async(h);
+        if (!pending) {
+            st.pcg_iterations += phase_linear_solve(h, lambda);
+            HIP_TRY(hipMemsetAsync(h->scalars.p + SLOT_PCGFLAG, 0, sizeof(double), h->stream));
+        }
         phase_trial(h, nullptr);
         read_scalars(h, sc);
+        if (pending) {
+            // identical on every rank: the flag is the ranks' sum, the state that of the same
+            // replicated solve
+            const PcgState ps = h->pcg_host[0];
+            if (h->trace_pcg)
+                fprintf(stderr, "pcg single launch: %d iterations, %.2f us in kernel, flag %d (all ranks %g)\n", ps.iter, ps.ticks * 0.01, ps.pad, sc[SLOT_PCGFLAG]);
+            const bool failed = sc[SLOT_PCGFLAG] != 0.0;
+            const bool converged = !(ps.rz > ps.tol2 * ps.rz0);
+            if (!failed && (converged || !h->dense_allowed)) {
+                h->fused_solves++;
+                st.pcg_iterations += ps.iter;
+            } else {
+                // breakdown, timeout, or out of iterations with the factorisation at hand: solve
+                // again launch by launch (which knows the dense fallback) and redo the trial step
+                if (failed) h->fused_fallbacks++;
+                st.pcg_iterations += phase_linear_solve(h, lambda, false);
+                HIP_TRY(hipMemsetAsync(h->scalars.p + SLOT_PCGFLAG, 0, sizeof(double), h->stream));
+                phase_trial(h, nullptr);
+                read_scalars(h, sc);
+            }
+        }
         st.nfev++;
         st.iterations++;
         const double model_cost = 0.5 * sc[SLOT_MODEL];

@@ -21,6 +21,7 @@ enum Slot {
     SLOT_X2_PT,         // sum |X|^2
     SLOT_TRIAL,         // sum r^2 at the trial point
     SLOT_NONFINITE,     // count of non-finite trial residuals
+    SLOT_PCGFLAG,       // non-zero: the single-launch PCG of this step must be redone (any rank)
     SLOT_STEP2_CAM,     // sum |dc|^2
     SLOT_X2_CAM,        // sum |t|^2 (+3 per camera for the rotation block)
     SLOT_GMAX_CAM,      // max |g_c|
@@ -54,6 +55,7 @@ struct FusedPcg {
     double2* dots;            // [4][gridDim.x] per-workgroup (r'r, w'r) records in rotating slots,
                               // then one abort word; all bits set = not written / no abort
     PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout
+    double* flag_slot;        // receives pad as a double (a scalar slot the ranks sum), may be null
     double tol2;
     int max_iter;
     long long timeout_ticks;  // of the 100 MHz wall clock: any later poll

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
         st.rz = gam; st.rz0 = gam0; st.tol2 = a.tol2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
         st.ticks = (long long)wall_clock64() - t_start;
         *a.out = st;
+        if (a.flag_slot) *a.flag_slot = (double)flag;
     }
 }
 
