@@ -79,3 +79,20 @@ def test_sharded_solve_larger_problem():
     for st, _, _ in out:
         assert st["iterations"] == ref.iterations
         assert abs(st["final_cost"] - ref.final_cost) <= 1e-9 * ref.final_cost
+
+
+@pytest.mark.parametrize("solver", list(SOLVERS))
+def test_sharded_solve_irregular_structure(solver):
+    # long tracks and points seen once all fall to rank 0, a camera with two chunks on every rank,
+    # a camera no rank observes
+    from test_gpu_irregular import irregular_problem
+    p = irregular_problem(33)
+    with E.Engine(**SOLVERS[solver]) as eng:
+        eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
+                        p["points_2d"], p["K"])
+        ref = eng.solve()
+    out = solve_sharded(p, 2, **SOLVERS[solver])
+    for st, poses, pts in out:
+        assert st["iterations"] == ref.iterations
+        assert abs(st["final_cost"] - ref.final_cost) <= 1e-8 * ref.final_cost
+        assert abs(o.cost(p, poses, pts) - st["final_cost"]) <= 1e-9 * st["final_cost"]
