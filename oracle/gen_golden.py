@@ -135,8 +135,58 @@ def record_triangulation(name, n, seed, noise_px):
     print(name, "mean errors", to.reprojection_errors(P1, X, p["x1"]).mean(), to.reprojection_errors(P2, X, p["x2"]).mean())
 
 
+def record_bal(name, prob, tight_nfev=200):
+    """Fixture for the 9-number camera of /root/reference/ba_test.py: inputs, oracle residuals,
+    SciPy's finite-difference Jacobian over the script's pattern, the script's least_squares call
+    and a tight solve.  Kept apart from the other fixtures by its ``bal_`` prefix."""
+    from oracle import bal_oracle as b
+    x0, args = b.pack(prob)
+    out = {k: prob[k] for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d")}
+    out["f0"] = b.fun(x0, *args)
+    A = b.bundle_adjustment_sparsity(*args[:4])
+    J = approx_derivative(b.fun, x0, method="2-point", f0=out["f0"], sparsity=A, args=args).tocsr()
+    J.sort_indices()
+    out["jac_data"], out["jac_indices"], out["jac_indptr"] = J.data, J.indices, J.indptr
+    r = b.solve_reference(prob)
+    out["ref_cost"] = r["cost"]; out["ref_status"] = r["status"]; out["ref_nfev"] = r["nfev"]
+    out["ref_njev"] = r["njev"]; out["ref_optimality"] = r["optimality"]; out["ref_initial_cost"] = r["initial_cost"]
+    out["ref_camera_params"] = r["camera_params"]; out["ref_points_3d"] = r["points_3d"]
+    t = b.solve_tight(prob, max_nfev=tight_nfev)
+    out["tight_cost"] = t["cost"]; out["tight_optimality"] = t["optimality"]; out["tight_nfev"] = t["nfev"]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: n_obs={prob['camera_indices'].size} cost0={r['initial_cost']:.6e} ref={r['cost']:.9e} "
+          f"status={r['status']} nfev={r['nfev']} tight={t['cost']:.9e} opt={t['optimality']:.2e}")
+
+
+def write_bal_text(path, prob):
+    """A data file in the layout of the published BAL problems (header, "cam point   x y" lines in
+    %.6e, then one %.16e number per line), bz2-compressed when the name says so."""
+    import bz2
+    lines = ["%d %d %d" % (prob["n_cameras"], prob["n_points"], prob["camera_indices"].size)]
+    for c, p, (x, y) in zip(prob["camera_indices"], prob["point_indices"], prob["points_2d"]):
+        lines.append("%d %d     %.6e %.6e" % (c, p, x, y))
+    lines += ["%.16e" % v for v in prob["camera_params"].ravel()]
+    lines += ["%.16e" % v for v in prob["points_3d"].ravel()]
+    opener = bz2.open if path.endswith(".bz2") else open
+    with opener(path, "wt") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def bal_fixtures():
+    record_bal("bal_tiny_5_60_200", syn.make_bal_problem(5, 60, 200, seed=41, window=5))
+    record_bal("bal_shuffled_9_200_700", syn.make_bal_problem(9, 200, 700, seed=42, window=9, shuffle=True))
+    p = syn.make_bal_problem(12, 300, 600, seed=43)
+    p["camera_params"][3, :3] = 0.0          # a zero rotation vector: 0/0 in the reference's rotate()
+    record_bal("bal_rho2_12_300_600", p)
+    write_bal_text(os.path.join(OUT, "bal_problem-6-40-pre.txt.bz2"), syn.make_bal_problem(6, 40, 130, seed=44, window=6))
+    write_bal_text(os.path.join(OUT, "bal_problem-4-10-pre.txt"), syn.make_bal_problem(4, 10, 25, seed=45, window=4))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--bal-only" in sys.argv:
+        bal_fixtures()
+        return
     if "--triangulation-only" in sys.argv:
         record_triangulation("tri_two_view_400", 400, seed=21, noise_px=0.5)
         record_triangulation("tri_exact_64", 64, seed=22, noise_px=0.0)
@@ -149,6 +199,7 @@ def main():
     record("ladybug_49_7776_31843", syn.make_shape("ladybug", seed=0), jac=False, tight_nfev=60)
     record_triangulation("tri_two_view_400", 400, seed=21, noise_px=0.5)
     record_triangulation("tri_exact_64", 64, seed=22, noise_px=0.0)
+    bal_fixtures()
 
 
 if __name__ == "__main__":

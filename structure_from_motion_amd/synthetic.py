@@ -164,3 +164,67 @@ def load_npz(path, K=None):
     prob["n_points"] = prob["points_3d"].shape[0]
     prob["n_obs"] = prob["camera_indices"].shape[0]
     return prob
+
+
+def _rotation_vectors(R):
+    """Rotation vectors (N, 3) of rotation matrices (N, 3, 3), angles in [0, pi].  The axis comes
+    from the symmetric part (k k' = (sym(R) - cos I) / (1 - cos)), which stays well conditioned up
+    to pi, and its sign from the skew part."""
+    R = np.asarray(R, dtype=np.float64)
+    c = np.clip((np.trace(R, axis1=1, axis2=2) - 1.0) * 0.5, -1.0, 1.0)
+    skew = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1) * 0.5
+    s = np.linalg.norm(skew, axis=1)
+    angle = np.arctan2(s, c)
+    out = np.zeros((R.shape[0], 3))
+    for n in range(R.shape[0]):
+        if angle[n] < 1e-6:
+            out[n] = skew[n]                      # sin(a) k ~ a k
+            continue
+        if c[n] > -0.5:
+            out[n] = skew[n] * (angle[n] / s[n])
+            continue
+        S = (0.5 * (R[n] + R[n].T) - c[n] * np.eye(3)) / (1.0 - c[n])
+        j = int(np.argmax(np.diag(S)))
+        k = S[:, j] / np.sqrt(S[j, j])
+        if np.dot(k, skew[n]) < 0:
+            k = -k
+        out[n] = k * angle[n]
+    return out
+
+
+def make_bal_problem(n_cameras, n_points, n_obs, seed=0, window=12, noise_px=0.5, rot_sigma=0.005,
+                     trans_sigma=0.01, point_sigma=0.01, focal_sigma=5.0, k_sigma=0.002, shuffle=False):
+    """The same ring scene for the 9-number camera of /root/reference/ba_test.py:78-89
+    (rotation vector, translation, f, k1, k2; the camera looks down its negative z axis and the
+    image point is -P[:2] / P[2] scaled by f (1 + k1 n + k2 n^2)).  ``camera_params`` is N_c x 9."""
+    rng = np.random.default_rng(seed)
+    R, t = ring_cameras(n_cameras, rng)
+    flip = np.diag([1.0, -1.0, -1.0])                 # points in front of the camera get P[2] < 0
+    R = np.einsum("ij,njk->nik", flip, R)
+    t = t @ flip.T
+    X = rng.uniform(-1.0, 1.0, (n_points, 3))
+    f = rng.uniform(900.0, 1500.0, n_cameras)
+    k1 = rng.normal(0.0, 0.05, n_cameras)
+    k2 = rng.normal(0.0, 0.02, n_cameras)
+    cam_idx, pt_idx = _visibility(n_cameras, n_points, n_obs, window, rng)
+
+    def proj(R, t, f, k1, k2, X):
+        P = np.einsum("nij,nj->ni", R[cam_idx], X[pt_idx]) + t[cam_idx]
+        p = -P[:, :2] / P[:, 2:3]
+        n = np.sum(p * p, axis=1)
+        return p * (f[cam_idx] * (1.0 + k1[cam_idx] * n + k2[cam_idx] * n * n))[:, None]
+
+    uv = proj(R, t, f, k1, k2, X) + rng.normal(0.0, noise_px, (n_obs, 2))
+    R0 = np.einsum("nij,njk->nik", _rodrigues(rng.normal(0.0, rot_sigma, (n_cameras, 3))), R)
+    cams0 = np.hstack([_rotation_vectors(R0), t + rng.normal(0.0, trans_sigma, t.shape),
+                       (f + rng.normal(0.0, focal_sigma, n_cameras))[:, None],
+                       (k1 + rng.normal(0.0, k_sigma, n_cameras))[:, None],
+                       (k2 + rng.normal(0.0, k_sigma, n_cameras))[:, None]])
+    X0 = X + rng.normal(0.0, point_sigma, X.shape)
+    if shuffle:
+        perm = rng.permutation(n_obs)
+        cam_idx, pt_idx, uv = cam_idx[perm], pt_idx[perm], uv[perm]
+    return {"camera_params": cams0, "points_3d": X0, "camera_indices": cam_idx, "point_indices": pt_idx,
+            "points_2d": uv, "n_cameras": n_cameras, "n_points": n_points, "n_obs": n_obs,
+            "true_camera_params": np.hstack([_rotation_vectors(R), t, f[:, None], k1[:, None], k2[:, None]]),
+            "true_points_3d": X}

@@ -17,6 +17,8 @@ def golden_names(need=None):
     for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         if os.path.basename(path).startswith("tri_") and need is None:
             continue                        # two-view triangulation fixtures: need="tri_X"
+        if os.path.basename(path).startswith("bal_"):
+            continue                        # 9-number camera fixtures: bal_golden_names()
         if need is None:
             out.append(os.path.basename(path)[:-4])
         else:
@@ -24,6 +26,10 @@ def golden_names(need=None):
                 if need in z.files:
                     out.append(os.path.basename(path)[:-4])
     return out
+
+
+def bal_golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "bal_*.npz")))
 
 
 def load_golden(name):
@@ -109,3 +115,43 @@ def identity_snapped_cameras(camera_params):
     s = np.sqrt((r * r).sum(axis=1) * 0.25)
     c = (np.trace(Q, axis1=1, axis2=2) - 1) * 0.5
     return np.flatnonzero((s < 1e-5) & (c > 0))
+
+
+def bal_blocks_to_reference_jacobian(jc, jp, camera_params, camera_indices, point_indices, n_points):
+    """CSR (2*n_obs) x (9*n_cameras + 3*n_points) Jacobian in the parameterisation of
+    /root/reference/ba_test.py:92-100 (rotation vector, translation, f, k1, k2) from the engine's
+    2x9 blocks, whose first six columns are (dw, dt) of the left perturbation
+    Y' = exp([dw]x) Y + dt.  A rotation-vector change dr turns the camera by dw = J_l(r) dr (left
+    Jacobian of SO(3)) and leaves the translation alone, i.e. dt = t x dw."""
+    cp = np.asarray(camera_params, dtype=np.float64)
+    n_cam = cp.shape[0]
+    ci = np.asarray(camera_indices)
+    pi = np.asarray(point_indices)
+    n_obs = ci.size
+    M = np.zeros((n_cam, 9, 9))
+    for c in range(n_cam):
+        r = cp[c, :3]
+        a = np.linalg.norm(r)
+        Kx = _skew(r)
+        if a < 1e-8:
+            Jl = np.eye(3) + 0.5 * Kx
+        else:
+            Jl = np.eye(3) + (1 - np.cos(a)) / a ** 2 * Kx + (a - np.sin(a)) / a ** 3 * Kx @ Kx
+        M[c, :3, :3] = Jl
+        M[c, 3:6, :3] = _skew(cp[c, 3:6]) @ Jl
+        M[c, 3:, 3:] = np.eye(6)
+    J9 = np.einsum("nki,nij->nkj", jc, M[ci])
+    vals = np.concatenate([J9, jp], axis=2)
+    cols_obs = np.concatenate([ci[:, None] * 9 + np.arange(9)[None, :],
+                               n_cam * 9 + pi[:, None] * 3 + np.arange(3)[None, :]], axis=1)
+    cols = np.repeat(cols_obs, 2, axis=0).ravel()
+    indptr = np.arange(0, 12 * 2 * n_obs + 1, 12)
+    J = csr_matrix((vals.reshape(-1), cols, indptr), shape=(2 * n_obs, 9 * n_cam + 3 * n_points))
+    J.sum_duplicates()
+    J.sort_indices()
+    return J
+
+
+def bal_golden_jacobian(g):
+    n = 9 * g["n_cameras"] + 3 * g["n_points"]
+    return csr_matrix((g["jac_data"], g["jac_indices"], g["jac_indptr"]), shape=(2 * g["n_obs"], n))

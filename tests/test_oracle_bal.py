@@ -1,0 +1,117 @@
+"""CPU: the oracle of the 9-number camera (/root/reference/ba_test.py) against its fixtures, and
+the package's file reader / writer against the oracle's line-by-line reader.  The reference holds
+no data file and no expected output for this script (it downloads its input), so these vectors pin
+the engine to the oracle only: parity unpinned."""
+import bz2
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize._numdiff import approx_derivative
+
+from helpers import GOLDEN_DIR, bal_golden_jacobian, bal_golden_names, load_golden
+from oracle import bal_oracle as b
+from structure_from_motion_amd import bal
+from structure_from_motion_amd import synthetic as syn
+
+FILES = ["bal_problem-6-40-pre.txt.bz2", "bal_problem-4-10-pre.txt"]
+
+
+def test_fixtures_exist():
+    assert len(bal_golden_names()) >= 3
+    for f in FILES:
+        assert os.path.exists(os.path.join(GOLDEN_DIR, f))
+
+
+@pytest.mark.parametrize("name", bal_golden_names())
+def test_oracle_reproduces_fixture_residuals_and_jacobian(name):
+    g = load_golden(name)
+    x0, args = b.pack(g)
+    f0 = b.fun(x0, *args)
+    assert np.array_equal(f0, g["f0"])
+    A = b.bundle_adjustment_sparsity(*args[:4])
+    assert A.shape == (2 * g["n_obs"], 9 * g["n_cameras"] + 3 * g["n_points"]) and A.nnz == 24 * g["n_obs"]
+    J = approx_derivative(b.fun, x0, method="2-point", f0=f0, sparsity=A, args=args).tocsr()
+    assert abs(J - bal_golden_jacobian(g)).max() <= 1e-9 * abs(J).max()
+
+
+def test_rotation_matches_matrix_exponential_and_zero_vector_is_identity():
+    rng = np.random.default_rng(0)
+    r = rng.normal(0, 1.0, (50, 3))
+    r[7] = 0.0
+    X = rng.normal(0, 1.0, (50, 3))
+    want = np.einsum("nij,nj->ni", syn._rodrigues(r), X)
+    assert np.abs(b.rotate(X, r) - want).max() <= 1e-14
+    assert np.array_equal(b.rotate(X, r)[7], X[7])
+    assert np.abs(bal.rotate(X, r) - want).max() <= 1e-14
+
+
+def test_projection_of_a_hand_computed_point():
+    # identity rotation, t = (0, 0, -2): P = (0.2, -0.4, -2), p = (0.1, -0.2), n = 0.05
+    cam = np.array([[0, 0, 0, 0, 0, -2.0, 100.0, 0.5, 2.0]])
+    uv = b.project(np.array([[0.2, -0.4, 0.0]]), cam)
+    scale = 100.0 * (1 + 0.5 * 0.05 + 2.0 * 0.05 ** 2)
+    assert np.allclose(uv, [[0.1 * scale, -0.2 * scale]], rtol=1e-15)
+
+
+def test_true_parameters_leave_only_the_observation_noise():
+    p = syn.make_bal_problem(8, 150, 500, seed=5, window=8)
+    c = b.cost(p, p["true_camera_params"], p["true_points_3d"])
+    assert 0.6 * 0.25 * 500 < c < 1.4 * 0.25 * 500          # E = n_obs * sigma^2, sigma = 0.5 px
+    assert b.cost(p) > 10 * c
+
+
+@pytest.mark.parametrize("fname", FILES)
+def test_reader_matches_the_line_by_line_reader(fname):
+    path = os.path.join(GOLDEN_DIR, fname)
+    want = b.read_bal_data(path)
+    got = bal.read_bal_data(path)
+    for w, g_ in zip(want, got):
+        assert w.shape == g_.shape and np.array_equal(w, g_)
+    assert got[2].dtype.kind == "i" and got[3].dtype.kind == "i"
+    assert got[0].shape[1] == 9 and got[1].shape[1] == 3 and got[4].shape[1] == 2
+
+
+def test_writer_round_trip_is_exact(tmp_path):
+    p = syn.make_bal_problem(5, 30, 100, seed=9, window=5, shuffle=True)
+    for name in ("p.txt", "p.txt.bz2"):
+        path = str(tmp_path / name)
+        bal.write_bal_data(path, p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"])
+        for src in (bal.read_bal_data(path), b.read_bal_data(path)):
+            cams, pts, ci, pi, uv = src
+            assert np.array_equal(cams, p["camera_params"]) and np.array_equal(pts, p["points_3d"])
+            assert np.array_equal(ci, p["camera_indices"]) and np.array_equal(pi, p["point_indices"])
+            assert np.array_equal(uv, p["points_2d"])
+
+
+def test_reader_rejects_damaged_files(tmp_path):
+    src = os.path.join(GOLDEN_DIR, "bal_problem-4-10-pre.txt")
+    text = open(src).read().split("\n")
+    cases = {"short": text[:-5], "long": text[:-1] + ["1.0", ""], "index": [text[0], "9 0 1.0 2.0"] + text[2:],
+             "fraction": [text[0], "0.5 0 1.0 2.0"] + text[2:], "empty": [""]}
+    for name, lines in cases.items():
+        path = str(tmp_path / (name + ".txt"))
+        with open(path, "w") as fh:
+            fh.write("\n".join(lines))
+        with pytest.raises(ValueError):
+            bal.read_bal_data(path)
+    with pytest.raises(OSError):
+        bal.read_bal_data(str(tmp_path / "absent.txt.bz2"))
+
+
+def test_sparsity_matches_the_pattern_of_the_script():
+    g = load_golden("bal_tiny_5_60_200")
+    A = bal.bundle_adjustment_sparsity(g["n_cameras"], g["n_points"], g["camera_indices"], g["point_indices"])
+    want = b.bundle_adjustment_sparsity(g["n_cameras"], g["n_points"], g["camera_indices"], g["point_indices"])
+    assert A.format == "lil" and (A.tocsr() != want).nnz == 0
+    i = 17
+    row = A.tocsr()[2 * i].indices
+    c, p = g["camera_indices"][i], g["point_indices"][i]
+    assert sorted(row) == sorted(list(range(9 * c, 9 * c + 9)) + list(range(45 + 3 * p, 45 + 3 * p + 3)))
+
+
+def test_reference_solve_reproduces_the_fixture():
+    g = load_golden("bal_tiny_5_60_200")
+    r = b.solve_reference(g)
+    assert r["status"] == int(g["ref_status"]) and r["nfev"] == int(g["ref_nfev"])
+    assert abs(r["cost"] - float(g["ref_cost"])) <= 1e-9 * float(g["ref_cost"])
