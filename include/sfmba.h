@@ -82,7 +82,19 @@ typedef struct sfmba_options {
      * on a breakdown of its recurrence or when its workgroups do not all become resident). */
     int32_t pcg_mode;
     int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
+    int32_t camera_model;     /* enum sfmba_camera_model; default SFMBA_CAMERA_PINHOLE */
 } sfmba_options;
+
+/* Camera models.  D = tangent numbers per camera (width of a Jacobian block and of every
+ * camera-sized vector of the diagnostics below), P = numbers per camera in camera_params.
+ *   SFMBA_CAMERA_PINHOLE  P = 12, D = 6: row-major 3x3 rotation block + translation, one fixed K for
+ *       all cameras, no distortion (bundle_adjustment.py:10-31); tangent (dw, dt).
+ *   SFMBA_CAMERA_BAL      P = 9, D = 9: rotation vector, translation, f, k1, k2 of the "Bundle
+ *       Adjustment in the Large" files; pixel = f (1 + k1 n + k2 n^2) p with p = -(R X + t)[:2] /
+ *       (R X + t)[2], n = |p|^2 (ba_test.py:62-100); tangent (dw, dt, df, dk1, dk2); K is not
+ *       read and may be NULL.  Solved with the matrix-free Schur complement and PCG only:
+ *       SFMBA_SOLVER_DENSE is refused, schur_mode and pcg_mode are ignored. */
+enum sfmba_camera_model { SFMBA_CAMERA_PINHOLE = 0, SFMBA_CAMERA_BAL = 1 };
 
 typedef struct sfmba_stats {
     int32_t status;           /* enum sfmba_status */
@@ -130,7 +142,9 @@ const char* sfmba_last_error(const sfmba_handle* h);
  * K[1][1], K[0][2], K[1][2] are used, as cv2.projectPoints does with empty distortion).
  * camera_params is n_cameras x 12 (row-major 3x3 rotation block, then translation); the 3x3
  * block is replaced by its polar orthogonal factor exactly as cv2.Rodrigues does at
- * bundle_adjustment.py:24.  Observations may come in any order. */
+ * bundle_adjustment.py:24.  Observations may come in any order.
+ * With SFMBA_CAMERA_BAL camera_params is n_cameras x 9 (the arrays read_bal_data returns,
+ * ba_test.py:17-42) and K is ignored. */
 int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
                       const double* camera_params, const double* points_3d,
                       const int64_t* camera_indices, const int64_t* point_indices,
@@ -153,7 +167,8 @@ int sfmba_residuals(sfmba_handle* h, double* out);
  * jac_cam is n_obs x 2 x 6 with columns (dw0, dw1, dw2, dt0, dt1, dt2) of the left
  * perturbation Y' = exp([dw]x) Y + dt of the camera-frame point Y = R X + t;
  * jac_pt is n_obs x 2 x 3 (d residual / d X).  They take the place of the 2-point finite
- * differences SciPy forms through jac_sparsity (bundle_adjustment.py:139-141). */
+ * differences SciPy forms through jac_sparsity (bundle_adjustment.py:139-141).
+ * With SFMBA_CAMERA_BAL jac_cam is n_obs x 2 x 9: the same six columns, then (df, dk1, dk2). */
 int sfmba_jacobian_blocks(sfmba_handle* h, double* jac_cam, double* jac_pt);
 
 /* Run the Levenberg-Marquardt solve from the current estimate: the replacement for the
@@ -161,7 +176,8 @@ int sfmba_jacobian_blocks(sfmba_handle* h, double* jac_cam, double* jac_pt);
 int sfmba_solve(sfmba_handle* h, sfmba_stats* stats);
 
 /* Current estimate in the reference's output layout (bundle_adjustment.py:147-150):
- * poses n_cameras x 12 (orthonormal rotation block + translation), points n_points x 3. */
+ * poses n_cameras x 12 (orthonormal rotation block + translation), points n_points x 3.
+ * With SFMBA_CAMERA_BAL: n_cameras x 9, the rotation vector with its angle in [0, pi]. */
 int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d);
 
 /* Mean reprojection error |projection - observation| (pixels) of every camera at the current
@@ -195,7 +211,8 @@ int sfmba_point_errors(sfmba_handle* h, int64_t n, const double* P, const double
 /* Linearise and damp with lambda.  Afterwards the blocks below can be read. */
 int sfmba_linearize(sfmba_handle* h, double lambda);
 /* U: n_cameras x 36 (J_c'J_c per camera), g_cam: n_cameras x 6, V: n_points x 9 (J_p'J_p per
- * point, owned points only on a partitioned handle), g_pt: n_points x 3.  Any may be NULL. */
+ * point, owned points only on a partitioned handle), g_pt: n_points x 3.  Any may be NULL.
+ * Here and below 6 and 36 read D and D*D for a camera model with D tangent numbers. */
 int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, double* g_pt);
 /* y = S x with S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p', x and y n_cameras x 6. */
 int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y);

@@ -149,13 +149,14 @@ __device__ __forceinline__ void spd3_inverse(const double* a, double* inv) {
     inv[5] = i22 * i22;
 }
 
-// In-register Cholesky of a symmetric positive definite 6x6 (full storage, row-major): A = L L'.
+// In-register Cholesky of a symmetric positive definite N x N (full storage, row-major): A = L L'.
 // Returns false when a pivot is not positive; A is destroyed, the lower triangle of Li receives
 // L^-1 (the strict upper triangle is left untouched).
-__device__ __forceinline__ bool spd6_chol_linv(double (&A)[6][6], double (&Li)[6][6]) {
+template <int N>
+__device__ __forceinline__ bool spd_chol_linv(double (&A)[N][N], double (&Li)[N][N]) {
     bool ok = true;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < N; ++j) {
         double d = A[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
@@ -163,7 +164,7 @@ __device__ __forceinline__ bool spd6_chol_linv(double (&A)[6][6], double (&Li)[6
         double l = sqrt(d), il = 1.0 / l;
         A[j][j] = l;
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
+        for (int i = j + 1; i < N; ++i) {
             double v = A[i][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
@@ -172,10 +173,10 @@ __device__ __forceinline__ bool spd6_chol_linv(double (&A)[6][6], double (&Li)[6
     }
     // Linv (lower) by forward substitution
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < N; ++j) {
         Li[j][j] = 1.0 / A[j][j];
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
+        for (int i = j + 1; i < N; ++i) {
             double v = 0.0;
 #pragma unroll
             for (int k = j; k < i; ++k) v -= A[i][k] * Li[k][j];
@@ -185,26 +186,31 @@ __device__ __forceinline__ bool spd6_chol_linv(double (&A)[6][6], double (&Li)[6
     return ok;
 }
 
-// Inverse of a symmetric positive definite 6x6 through its Cholesky factor: Ainv = Li' Li.
+// Inverse of a symmetric positive definite N x N through its Cholesky factor: Ainv = Li' Li.
 // Returns false when a pivot is not positive; A is destroyed.
-__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6], double (&Li)[6][6]) {
-    const bool ok = spd6_chol_linv(A, Li);
+template <int N>
+__device__ __forceinline__ bool spd_inverse(double (&A)[N][N], double (&Ainv)[N][N], double (&Li)[N][N]) {
+    const bool ok = spd_chol_linv(A, Li);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = i; j < 6; ++j) {
+        for (int j = i; j < N; ++j) {
             double v = 0.0;
 #pragma unroll
-            for (int k = j; k < 6; ++k) v += Li[k][i] * Li[k][j];
+            for (int k = j; k < N; ++k) v += Li[k][i] * Li[k][j];
             Ainv[i][j] = v;
             Ainv[j][i] = v;
         }
     return ok;
 }
-__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6]) {
-    double Li[6][6];
-    return spd6_inverse(A, Ainv, Li);
+template <int N>
+__device__ __forceinline__ bool spd_inverse(double (&A)[N][N], double (&Ainv)[N][N]) {
+    double Li[N][N];
+    return spd_inverse(A, Ainv, Li);
 }
+__device__ __forceinline__ bool spd6_chol_linv(double (&A)[6][6], double (&Li)[6][6]) { return spd_chol_linv(A, Li); }
+__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6], double (&Li)[6][6]) { return spd_inverse(A, Ainv, Li); }
+__device__ __forceinline__ bool spd6_inverse(double (&A)[6][6], double (&Ainv)[6][6]) { return spd_inverse(A, Ainv); }
 
 // exp([w]x) as a row-major 3x3.
 __device__ __forceinline__ void so3_exp(const double* w, double* E) {
@@ -229,6 +235,211 @@ __device__ __forceinline__ void so3_exp(const double* w, double* E) {
     E[7] = a * w[0] + b * w[1] * w[2];
     E[8] = 1.0 + b * (w[2] * w[2] - t2);
 }
+
+// ---- camera models ---------------------------------------------------------------------------
+// A model names the camera record in HBM, the size of a camera's tangent space and the per-
+// observation arithmetic.  Every model perturbs the pose from the left, Y' = exp([dw]x) Y + dt,
+// so that the pose columns of a camera block depend on the seed (x, y, 1/Z) alone; what differs
+// is the map from the normalised image point to pixels and any further per-camera parameters.
+enum CameraModel { MODEL_PINHOLE = 0, MODEL_BAL = 1 };
+
+// The reference's bundle adjustment (/root/reference/bundle_adjustment.py:10-31): one shared K,
+// no distortion, tangent (dw, dt).
+struct Pinhole {
+    static constexpr int ND = 6;              // tangent dimensions of a camera
+    static constexpr int NU = 21;             // packed upper triangle of an ND x ND block
+    static constexpr int NV = 27;             // NU + ND: what a chunk accumulates per camera
+    static constexpr int CW = 6;              // 16-byte words of a camera record
+    using Cam = sfmba::Cam;
+    struct Obs { Seed s; Intr K; };
+    static __device__ __forceinline__ Cam load(const double2* __restrict__ cams, int c) { return load_cam(cams, c); }
+    // rotation only (the translation is left unset)
+    static __device__ __forceinline__ Cam load_rot(const double2* __restrict__ cams, int c) {
+        const double2* p = cams + 6 * (size_t)c;
+        const double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
+        Cam k;
+        k.q[0] = a0.x; k.q[1] = a0.y; k.q[2] = a1.x; k.q[3] = a1.y; k.q[4] = a2.x; k.q[5] = a2.y;
+        k.q[6] = a3.x; k.q[7] = a3.y; k.q[8] = a4.x; k.t[0] = k.t[1] = k.t[2] = 0.0;
+        return k;
+    }
+    static __device__ __forceinline__ void store(double2* __restrict__ cams, int c, const Cam& k) {
+        double2* dst = cams + 6 * (size_t)c;
+        dst[0] = make_double2(k.q[0], k.q[1]); dst[1] = make_double2(k.q[2], k.q[3]); dst[2] = make_double2(k.q[4], k.q[5]);
+        dst[3] = make_double2(k.q[6], k.q[7]); dst[4] = make_double2(k.q[8], k.t[0]); dst[5] = make_double2(k.t[1], k.t[2]);
+    }
+    static __device__ __forceinline__ Seed seed(const Cam& k, double X0, double X1, double X2) { return project_seed(k, X0, X1, X2); }
+    static __device__ __forceinline__ Obs obs(const Seed& s, const Cam&, const Intr& K) { return Obs{s, K}; }
+    static __device__ __forceinline__ void residual(const Obs& o, double u, double v, double& ru, double& rv) { sfmba::residual(o.s, o.K, u, v, ru, rv); }
+    static __device__ __forceinline__ void jac_cam(const Obs& o, double* jc) { sfmba::jac_cam(o.s, o.K, jc); }
+    static __device__ __forceinline__ void jac_pt(const Obs& o, const double* q, double* a, double* b) { sfmba::jac_pt(o.s, o.K, q, a, b); }
+    static __device__ __forceinline__ void jc_times(const Obs& o, const double* d, double& w0, double& w1) { sfmba::jc_times(o.s, o.K, d, w0, w1); }
+    static __device__ __forceinline__ void jpT_times_acc(const Obs& o, const double* q, double w0, double w1, double* out) { sfmba::jpT_times_acc(o.s, o.K, q, w0, w1, out); }
+    static __device__ __forceinline__ void jp_times(const Obs& o, const double* q, const double* d, double& w0, double& w1) { sfmba::jp_times(o.s, o.K, q, d, w0, w1); }
+    static __device__ __forceinline__ void jcT_times_acc(const Obs& o, double w0, double w1, double* out) { sfmba::jcT_times_acc(o.s, o.K, w0, w1, out); }
+    // the camera moved by the tangent step w; returns the camera's share of |x|^2 (the raw
+    // 12-number camera: 3 for the rotation entries, then the translation)
+    static __device__ __forceinline__ Cam retract(const Cam& k, const double* w, double& x2) {
+        double E[9];
+        so3_exp(w, E);
+        Cam o;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                o.q[3 * i + j] = E[3 * i] * k.q[j] + E[3 * i + 1] * k.q[3 + j] + E[3 * i + 2] * k.q[6 + j];
+            o.t[i] = E[3 * i] * k.t[0] + E[3 * i + 1] * k.t[1] + E[3 * i + 2] * k.t[2] + w[3 + i];
+        }
+        x2 = 3.0 + k.t[0] * k.t[0] + k.t[1] * k.t[1] + k.t[2] * k.t[2];
+        return o;
+    }
+};
+
+// The camera of the "Bundle Adjustment in the Large" files (/root/reference/ba_test.py:78-89):
+// P = R X + t, p = -P[:2] / P[2], pixel = f (1 + k1 |p|^2 + k2 |p|^4) p, with f, k1, k2 per
+// camera and estimated: tangent (dw, dt, df, dk1, dk2).  The rotation is kept as a matrix in HBM
+// (the rotation vector of the file is converted on the host).
+struct Bal {
+    static constexpr int ND = 9;
+    static constexpr int NU = 45;
+    static constexpr int NV = 54;
+    static constexpr int CW = 8;              // q[9] t[3] f k1 k2 pad
+    struct Cam { double q[9]; double t[3]; double f, k1, k2; };
+    // a = d pixel / d (x, y) (symmetric 2x2), g = (r, f n, f n^2): d pixel / d (f, k1, k2) = -(x, y) g
+    struct Obs { Seed s; double a00, a01, a11, g0, g1, g2, fr; };
+    static __device__ __forceinline__ Cam load(const double2* __restrict__ cams, int c) {
+        const double2* p = cams + 8 * (size_t)c;
+        const double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
+        Cam k;
+        k.q[0] = a0.x; k.q[1] = a0.y; k.q[2] = a1.x; k.q[3] = a1.y; k.q[4] = a2.x; k.q[5] = a2.y;
+        k.q[6] = a3.x; k.q[7] = a3.y; k.q[8] = a4.x; k.t[0] = a4.y; k.t[1] = a5.x; k.t[2] = a5.y;
+        k.f = a6.x; k.k1 = a6.y; k.k2 = a7.x;
+        return k;
+    }
+    static __device__ __forceinline__ Cam load_rot(const double2* __restrict__ cams, int c) {
+        const double2* p = cams + 8 * (size_t)c;
+        const double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a6 = p[6], a7 = p[7];
+        Cam k;
+        k.q[0] = a0.x; k.q[1] = a0.y; k.q[2] = a1.x; k.q[3] = a1.y; k.q[4] = a2.x; k.q[5] = a2.y;
+        k.q[6] = a3.x; k.q[7] = a3.y; k.q[8] = a4.x; k.t[0] = k.t[1] = k.t[2] = 0.0;
+        k.f = a6.x; k.k1 = a6.y; k.k2 = a7.x;
+        return k;
+    }
+    static __device__ __forceinline__ void store(double2* __restrict__ cams, int c, const Cam& k) {
+        double2* dst = cams + 8 * (size_t)c;
+        dst[0] = make_double2(k.q[0], k.q[1]); dst[1] = make_double2(k.q[2], k.q[3]); dst[2] = make_double2(k.q[4], k.q[5]);
+        dst[3] = make_double2(k.q[6], k.q[7]); dst[4] = make_double2(k.q[8], k.t[0]); dst[5] = make_double2(k.t[1], k.t[2]);
+        dst[6] = make_double2(k.f, k.k1); dst[7] = make_double2(k.k2, 0.0);
+    }
+    // no guard against Z == 0: the reference divides (ba_test.py:82) and SciPy then refuses the
+    // non-finite residual
+    static __device__ __forceinline__ Seed seed(const Cam& k, double X0, double X1, double X2) {
+        const double Y0 = k.q[0] * X0 + k.q[1] * X1 + k.q[2] * X2 + k.t[0];
+        const double Y1 = k.q[3] * X0 + k.q[4] * X1 + k.q[5] * X2 + k.t[1];
+        const double Y2 = k.q[6] * X0 + k.q[7] * X1 + k.q[8] * X2 + k.t[2];
+        Seed s;
+        s.iz = 1.0 / Y2;
+        s.x = Y0 * s.iz;
+        s.y = Y1 * s.iz;
+        return s;
+    }
+    static __device__ __forceinline__ Obs obs(const Seed& s, const Cam& k, const Intr&) {
+        const double n = s.x * s.x + s.y * s.y;
+        const double r = 1.0 + n * (k.k1 + k.k2 * n);
+        const double rp2 = 2.0 * (k.k1 + 2.0 * k.k2 * n);         // 2 dr/dn
+        Obs o;
+        o.s = s;
+        o.a00 = -k.f * (r + rp2 * s.x * s.x);
+        o.a01 = -k.f * rp2 * s.x * s.y;
+        o.a11 = -k.f * (r + rp2 * s.y * s.y);
+        o.g0 = r; o.g1 = k.f * n; o.g2 = k.f * n * n; o.fr = k.f * r;
+        return o;
+    }
+    static __device__ __forceinline__ void residual(const Obs& o, double u, double v, double& ru, double& rv) {
+        ru = -o.fr * o.s.x - u;
+        rv = -o.fr * o.s.y - v;
+    }
+    // rows of d (x, y) / d (dw, dt): the pinhole rows with unit focal lengths
+    static __device__ __forceinline__ void normalised_rows(const Seed& s, double* nx, double* ny) {
+        nx[0] = -s.x * s.y; nx[1] = 1.0 + s.x * s.x; nx[2] = -s.y; nx[3] = s.iz; nx[4] = 0.0; nx[5] = -s.x * s.iz;
+        ny[0] = -(1.0 + s.y * s.y); ny[1] = s.x * s.y; ny[2] = s.x; ny[3] = 0.0; ny[4] = s.iz; ny[5] = -s.y * s.iz;
+    }
+    // jc[0..8] is the u row, jc[9..17] the v row
+    static __device__ __forceinline__ void jac_cam(const Obs& o, double* jc) {
+        double nx[6], ny[6];
+        normalised_rows(o.s, nx, ny);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            jc[i] = o.a00 * nx[i] + o.a01 * ny[i];
+            jc[9 + i] = o.a01 * nx[i] + o.a11 * ny[i];
+        }
+        jc[6] = -o.s.x * o.g0; jc[7] = -o.s.x * o.g1; jc[8] = -o.s.x * o.g2;
+        jc[15] = -o.s.y * o.g0; jc[16] = -o.s.y * o.g1; jc[17] = -o.s.y * o.g2;
+    }
+    static __device__ __forceinline__ void jac_pt(const Obs& o, const double* q, double* a, double* b) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double an = o.s.iz * (q[k] - o.s.x * q[6 + k]);
+            const double bn = o.s.iz * (q[3 + k] - o.s.y * q[6 + k]);
+            a[k] = o.a00 * an + o.a01 * bn;
+            b[k] = o.a01 * an + o.a11 * bn;
+        }
+    }
+    static __device__ __forceinline__ void jc_times(const Obs& o, const double* d, double& w0, double& w1) {
+        const Seed& s = o.s;
+        const double v0 = d[1] - d[2] * s.y + d[3] * s.iz;
+        const double v1 = d[2] * s.x - d[0] + d[4] * s.iz;
+        const double v2 = d[0] * s.y - d[1] * s.x + d[5] * s.iz;
+        const double n0 = v0 - s.x * v2, n1 = v1 - s.y * v2;
+        const double e = o.g0 * d[6] + o.g1 * d[7] + o.g2 * d[8];
+        w0 = o.a00 * n0 + o.a01 * n1 - s.x * e;
+        w1 = o.a01 * n0 + o.a11 * n1 - s.y * e;
+    }
+    static __device__ __forceinline__ void jpT_times_acc(const Obs& o, const double* q, double w0, double w1, double* out) {
+        const double e0 = o.s.iz * (o.a00 * w0 + o.a01 * w1), e1 = o.s.iz * (o.a01 * w0 + o.a11 * w1);
+        const double e2 = -(o.s.x * e0 + o.s.y * e1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] += q[k] * e0 + q[3 + k] * e1 + q[6 + k] * e2;
+    }
+    static __device__ __forceinline__ void jp_times(const Obs& o, const double* q, const double* d, double& w0, double& w1) {
+        const double y0 = q[0] * d[0] + q[1] * d[1] + q[2] * d[2];
+        const double y1 = q[3] * d[0] + q[4] * d[1] + q[5] * d[2];
+        const double y2 = q[6] * d[0] + q[7] * d[1] + q[8] * d[2];
+        const double n0 = o.s.iz * (y0 - o.s.x * y2), n1 = o.s.iz * (y1 - o.s.y * y2);
+        w0 = o.a00 * n0 + o.a01 * n1;
+        w1 = o.a01 * n0 + o.a11 * n1;
+    }
+    static __device__ __forceinline__ void jcT_times_acc(const Obs& o, double w0, double w1, double* out) {
+        const Seed& s = o.s;
+        const double a = o.a00 * w0 + o.a01 * w1, b = o.a01 * w0 + o.a11 * w1;
+        out[0] += -a * s.x * s.y - b * (1.0 + s.y * s.y);
+        out[1] += a * (1.0 + s.x * s.x) + b * s.x * s.y;
+        out[2] += -a * s.y + b * s.x;
+        out[3] += a * s.iz;
+        out[4] += b * s.iz;
+        out[5] += -(a * s.x + b * s.y) * s.iz;
+        const double e = -(s.x * w0 + s.y * w1);
+        out[6] += o.g0 * e; out[7] += o.g1 * e; out[8] += o.g2 * e;
+    }
+    // x2: the camera's share of |x|^2 in the file's parameters (rotation vector, t, f, k1, k2)
+    static __device__ __forceinline__ Cam retract(const Cam& k, const double* w, double& x2) {
+        double E[9];
+        so3_exp(w, E);
+        Cam o;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                o.q[3 * i + j] = E[3 * i] * k.q[j] + E[3 * i + 1] * k.q[3 + j] + E[3 * i + 2] * k.q[6 + j];
+            o.t[i] = E[3 * i] * k.t[0] + E[3 * i + 1] * k.t[1] + E[3 * i + 2] * k.t[2] + w[3 + i];
+        }
+        o.f = k.f + w[6]; o.k1 = k.k1 + w[7]; o.k2 = k.k2 + w[8];
+        const double rx = k.q[7] - k.q[5], ry = k.q[2] - k.q[6], rz = k.q[3] - k.q[1];
+        const double sn = 0.5 * sqrt(rx * rx + ry * ry + rz * rz), cs = 0.5 * (k.q[0] + k.q[4] + k.q[8] - 1.0);
+        const double ang = atan2(sn, cs);
+        x2 = ang * ang + k.t[0] * k.t[0] + k.t[1] * k.t[1] + k.t[2] * k.t[2] + k.f * k.f + k.k1 * k.k1 + k.k2 * k.k2;
+        return o;
+    }
+};
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  This maps the
 // hardware block id to a logical one so that each XCD works on one contiguous range of the
@@ -368,21 +579,23 @@ __device__ __forceinline__ void wave_sum_lds(const double (&acc)[N], double* buf
 }
 
 // ---- camera-sized dense helpers --------------------------------------------------------------
-// y = (U + lambda clamp(diag U)) x with U packed upper (21); y = M x with M full row-major 6x6.
-__device__ __forceinline__ void ustar_times(const double* U, double lambda, const double* x, double* y) {
-    double A[6][6];
+// y = (U + lambda clamp(diag U)) x with U packed upper (N (N + 1) / 2); y = M x with M full
+// row-major N x N.
+template <int N>
+__device__ __forceinline__ void ustar_times(const double* U, double lambda, const double (&x)[N], double (&y)[N]) {
+    double A[N][N];
     int n = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = i; j < 6; ++j) { A[i][j] = U[n]; A[j][i] = U[n]; ++n; }
+        for (int j = i; j < N; ++j) { A[i][j] = U[n]; A[j][i] = U[n]; ++n; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) A[i][i] += lambda * fmin(fmax(A[i][i], 1e-6), 1e32);
+    for (int i = 0; i < N; ++i) A[i][i] += lambda * fmin(fmax(A[i][i], 1e-6), 1e32);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < N; ++i) {
         double v = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) v += A[i][j] * x[j];
+        for (int j = 0; j < N; ++j) v += A[i][j] * x[j];
         y[i] = v;
     }
 }

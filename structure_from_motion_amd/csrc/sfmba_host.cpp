@@ -211,6 +211,8 @@ struct sfmba_handle {
     int64_t pt_lo = 0, pt_hi = 0;          // owned point range
     int n_pts = 0, n_obs = 0, n_chunks = 0, nb_cam = 0;
     int chunk = kChunk;
+    int model = MODEL_PINHOLE;             // camera model of the loaded problem
+    int cd = 6, cv = 27, cw = 6;           // per camera: tangent numbers, packed upper + gradient, 16-byte words
     std::vector<int> new2old;              // internal (renumbered) local point id -> caller's local point id
 
     // device memory
@@ -297,6 +299,7 @@ struct SetupTrace {
 void refresh_dev(H* h) {
     Dev& d = h->dev;
     d.n_cam = (int)h->n_cam; d.n_pts = h->n_pts; d.n_obs = h->n_obs; d.n_chunks = h->n_chunks;
+    d.model = h->model;
     d.pt_ptr = h->pt_ptr.p; d.pm_cam = h->pm_cam.p; d.pm_pt = h->pm_pt.p; d.pm_orig = h->pm_orig.p;
     d.pm_uv = h->pm_uv.p; d.cm_pt = h->cm_pt.p; d.cm_uv = h->cm_uv.p;
     d.chunk_cam = h->chunk_cam.p; d.chunk_beg = h->chunk_beg.p; d.cam_chunk_ptr = h->cam_chunk_ptr.p;
@@ -408,16 +411,16 @@ void phase_linearize(H* h, double lambda = 0.0) {
     launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream);
     h->damped_lambda = lambda > 0.0 ? lambda : -1.0;
     launch_lin_cm(h->dev, h->stream);
-    launch_chunk_reduce(h->dev, 27, h->UG.p, h->stream);
+    launch_chunk_reduce(h->dev, h->cv, h->UG.p, h->stream);
     if (h->has_comm()) {
         // one collective for the camera blocks and the gradient maximum over the points: the
         // maximum travels as one slot per rank behind the blocks (a sum all-reduce of slots of
         // which only one rank fills each)
         const int nr = h->opt.nranks;
-        double* slots = h->UG.p + (size_t)h->n_cam * 27;
+        double* slots = h->UG.p + (size_t)h->n_cam * h->cv;
         HIP_TRY(hipMemsetAsync(slots, 0, nr * sizeof(double), h->stream));
         HIP_TRY(hipMemcpyAsync(slots + h->opt.rank, h->scalars.p + SLOT_GMAX_PT, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        allreduce(h, h->UG.p, (size_t)h->n_cam * 27 + nr);
+        allreduce(h, h->UG.p, (size_t)h->n_cam * h->cv + nr);
     }
     launch_gmax_cam(h->dev, h->stream);
     h->linearized = false;
@@ -457,8 +460,8 @@ void phase_damp(H* h, double lambda) {
         Scope t(h, F_DAMP);
         if (h->damped_lambda != lambda) launch_damp_pm(h->dev, lambda, h->stream);
         launch_sdiag_cm(h->dev, h->stream);
-        launch_chunk_reduce(h->dev, 27, h->T.p, h->stream);
-        allreduce(h, h->T.p, (size_t)h->n_cam * 27);
+        launch_chunk_reduce(h->dev, h->cv, h->T.p, h->stream);
+        allreduce(h, h->T.p, (size_t)h->n_cam * h->cv);
         launch_precond(h->dev, lambda, h->stream);
     }
     h->linearized = true;
@@ -478,9 +481,9 @@ void schur_product(H* h, const double* x, const PcgState* state) {
     }
     {
         Scope t(h, F_PCGVEC);
-        launch_chunk_reduce(h->dev, 6, h->qS.p, h->stream);
+        launch_chunk_reduce(h->dev, h->cd, h->qS.p, h->stream);
     }
-    allreduce(h, h->qS.p, (size_t)h->n_cam * 6);
+    allreduce(h, h->qS.p, (size_t)h->n_cam * h->cd);
 }
 
 // Block-Jacobi PCG on S dc = rhs; result in px.  Returns the iteration count.
@@ -661,7 +664,7 @@ double read_lin_scalars(H* h, double* sc) {
     std::vector<double> slots;
     if (h->has_comm()) {
         slots.resize(h->opt.nranks);
-        HIP_TRY(hipMemcpyAsync(slots.data(), h->UG.p + (size_t)h->n_cam * 27, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(slots.data(), h->UG.p + (size_t)h->n_cam * h->cv, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     read_scalars(h, sc);
     double m = sc[SLOT_GMAX_PT];
@@ -682,7 +685,7 @@ void do_solve(H* h, sfmba_stats* out) {
     HIP_TRY(hipSetDevice(h->device));
     const sfmba_options& o = h->opt;
     const double ftol = o.ftol, xtol = o.xtol, gtol = o.gtol;
-    const int64_t n_par = 12 * h->n_cam + 3 * h->n_pts_all;
+    const int64_t n_par = (h->model == MODEL_BAL ? 9 : 12) * h->n_cam + 3 * h->n_pts_all;
     const int64_t max_nfev = o.max_nfev > 0 ? o.max_nfev : 100 * n_par;
     const int max_it = o.max_iterations > 0 ? o.max_iterations : 200;
     double lambda = o.initial_lambda > 0 ? o.initial_lambda : 1e-4;
@@ -813,7 +816,54 @@ void do_solve(H* h, sfmba_stats* out) {
 }
 
 // ---- problem packing ----------------------------------------------------------------------
+// Rotation matrix of a rotation vector by Rodrigues' formula, as /root/reference/ba_test.py:62-75
+// applies it to a point: a zero vector is the identity.
+void rotation_of_vector(const double* r, double* Q) {
+    const double a = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double k[3] = {0.0, 0.0, 0.0};
+    if (a > 0.0) for (int i = 0; i < 3; ++i) k[i] = r[i] / a;
+    const double c = std::cos(a), s = std::sin(a), v = 1.0 - c;
+    Q[0] = c + v * k[0] * k[0];         Q[1] = v * k[0] * k[1] - s * k[2];  Q[2] = v * k[0] * k[2] + s * k[1];
+    Q[3] = v * k[1] * k[0] + s * k[2];  Q[4] = c + v * k[1] * k[1];         Q[5] = v * k[1] * k[2] - s * k[0];
+    Q[6] = v * k[2] * k[0] - s * k[1];  Q[7] = v * k[2] * k[1] + s * k[0];  Q[8] = c + v * k[2] * k[2];
+}
+
+// Rotation vector (angle in [0, pi]) of a rotation matrix.  Away from pi the axis is the skew part;
+// near pi, where that vanishes, it comes from the symmetric part (k k' = (sym(Q) - c I) / (1 - c))
+// with the sign the skew part indicates.
+void vector_of_rotation(const double* Q, double* r) {
+    const double sx = 0.5 * (Q[7] - Q[5]), sy = 0.5 * (Q[2] - Q[6]), sz = 0.5 * (Q[3] - Q[1]);
+    const double s = std::sqrt(sx * sx + sy * sy + sz * sz);
+    const double c = 0.5 * (Q[0] + Q[4] + Q[8] - 1.0);
+    const double a = std::atan2(s, c);
+    if (a < 1e-7) { r[0] = sx; r[1] = sy; r[2] = sz; return; }
+    if (c > -0.5) { const double f = a / s; r[0] = sx * f; r[1] = sy * f; r[2] = sz * f; return; }
+    double S[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) S[i][j] = (0.5 * (Q[3 * i + j] + Q[3 * j + i]) - (i == j ? c : 0.0)) / (1.0 - c);
+    int j = 0;
+    if (S[1][1] > S[j][j]) j = 1;
+    if (S[2][2] > S[j][j]) j = 2;
+    const double n = std::sqrt(S[j][j]);
+    double k[3] = {S[0][j] / n, S[1][j] / n, S[2][j] / n};
+    if (k[0] * sx + k[1] * sy + k[2] * sz < 0.0) for (int i = 0; i < 3; ++i) k[i] = -k[i];
+    for (int i = 0; i < 3; ++i) r[i] = k[i] * a;
+}
+
 void pack_cameras(H* h, const double* camera_params, std::vector<double2>& out) {
+    if (h->model == MODEL_BAL) {
+        out.resize((size_t)h->n_cam * 8);
+        for (int64_t c = 0; c < h->n_cam; ++c) {
+            const double* cp = camera_params + 9 * c;
+            for (int i = 0; i < 9; ++i)
+                if (!std::isfinite(cp[i])) fail(SFMBA_ERR_NONFINITE, "camera_params[%lld] is not finite", (long long)c);
+            double Q[9];
+            rotation_of_vector(cp, Q);
+            const double v[16] = {Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7], Q[8], cp[3], cp[4], cp[5], cp[6], cp[7], cp[8], 0.0};
+            for (int i = 0; i < 8; ++i) out[8 * c + i] = make_double2(v[2 * i], v[2 * i + 1]);
+        }
+        return;
+    }
     out.resize((size_t)h->n_cam * 6);
     for (int64_t c = 0; c < h->n_cam; ++c) {
         double Q[9];
@@ -897,6 +947,16 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     if (const char* e = getenv("SFMBA_LINEAR_SOLVER")) lin = atoi(e);
     const int dense_max = h->opt.dense_max_dim > 0 ? h->opt.dense_max_dim : 1536;
     const bool want_dense = lin == SFMBA_SOLVER_DENSE;
+    if (h->model != MODEL_PINHOLE) {
+        // the explicit reduced matrix, its single-launch PCG and the dense factorisation are
+        // written for 6x6 camera blocks: other models use the matrix-free product
+        if (want_dense) fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: not available for this camera model");
+        h->dense_allowed = h->use_dense = h->explicit_schur = false;
+        h->fused_pcg = false;
+        h->n_ublk = h->n_pchunks = h->nnzb = 0;
+        h->n_pairs = 0;
+        return;
+    }
     h->dense_allowed = lin == SFMBA_SOLVER_AUTO && 6 * (int64_t)n_cam <= dense_max;
     if (6 * (int64_t)n_cam > 16384 && lin == SFMBA_SOLVER_DENSE)
         fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)(6 * (int64_t)n_cam));
@@ -1127,7 +1187,10 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
                     const double* points_3d, const int64_t* cam_idx, const int64_t* pt_idx,
                     const double* points_2d, const double* K) {
     if (n_cam <= 0 || n_pts <= 0 || n_obs < 0) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes must be positive");
-    if (!camera_params || !points_3d || !K || (n_obs > 0 && (!cam_idx || !pt_idx || !points_2d)))
+    const int model = h->opt.camera_model;
+    if (model != SFMBA_CAMERA_PINHOLE && model != SFMBA_CAMERA_BAL)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: unknown camera model %d", model);
+    if (!camera_params || !points_3d || (!K && model == SFMBA_CAMERA_PINHOLE) || (n_obs > 0 && (!cam_idx || !pt_idx || !points_2d)))
         fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: null array");
     if (n_obs > 2000000000LL || n_pts > 2000000000LL || n_cam > 50000000LL)
         fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes exceed 32-bit indexing");
@@ -1141,7 +1204,10 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
             fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)pt_idx[i], (long long)n_pts);
     }
     h->n_cam = n_cam; h->n_pts_all = n_pts; h->n_obs_all = n_obs;
-    h->dev.K = Intr{K[0], K[4], K[2], K[5]};
+    h->model = model == SFMBA_CAMERA_BAL ? MODEL_BAL : MODEL_PINHOLE;
+    h->cd = cam_dim(h->model); h->cv = cam_sums(h->model); h->cw = cam_words(h->model);
+    h->dev.model = h->model;
+    h->dev.K = K ? Intr{K[0], K[4], K[2], K[5]} : Intr{1.0, 1.0, 0.0, 0.0};
 
     // observations per point, then the owned point range: contiguous, equal observation share
     std::vector<int> cnt((size_t)n_pts + 1, 0);
@@ -1251,15 +1317,17 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->V.alloc((size_t)np * 6); h->gp.alloc((size_t)np * 4); h->Vinv.alloc((size_t)np * 6);
     h->V.zero(st); h->gp.zero(st);      // points without observations are never written
     h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
-    h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * 27);
-    h->UG.alloc((size_t)n_cam * 27 + (size_t)std::max(1, h->opt.nranks)); h->T.alloc((size_t)n_cam * 27);
+    const size_t cd = (size_t)h->cd, cv = (size_t)h->cv;
+    h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * cv);
+    h->UG.alloc((size_t)n_cam * cv + (size_t)std::max(1, h->opt.nranks)); h->T.alloc((size_t)n_cam * cv);
     h->UG.zero(h->stream);
-    h->Minv.alloc((size_t)n_cam * 36); h->rhs.alloc((size_t)n_cam * 6);
-    for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp[0], &h->pp[1], &h->pq, &h->qS}) b->alloc((size_t)n_cam * 6);
+    h->Minv.alloc((size_t)n_cam * cd * cd); h->rhs.alloc((size_t)n_cam * cd);
+    for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp[0], &h->pp[1], &h->pq, &h->qS}) b->alloc((size_t)n_cam * cd);
     h->nb_bsr = bsr_blocks_host((int)n_cam);
     {
         Dev t{};
         t.n_cam = (int)n_cam;
+        t.model = h->model;
         h->dot_off = std::max(h->nb_cam, pcg_spmv_blocks(t));       // p'q partials, then r'z partials
         h->pcg.alloc(2); h->dot_part.alloc((size_t)h->dot_off + pcg_update_blocks(t));
     }
@@ -1270,7 +1338,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     else { h->pm_seed.alloc((size_t)no); h->pm_rv.alloc((size_t)no); }
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
     h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
-    h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * 36));
+    h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * (int64_t)(cd * cd)));
     HIP_TRY(hipStreamSynchronize(st));
     do_set_params(h, camera_params, points_3d);
     tr.lap("parameters");
@@ -1320,6 +1388,7 @@ void sfmba_default_options(sfmba_options* o) {
     o->linear_solver = SFMBA_SOLVER_AUTO; o->dense_max_dim = 1536; o->verbose = 0; o->profile = 0; o->device = -1;
     o->rank = 0; o->nranks = 1;
     o->pcg_mode = 0; o->pcg_blocks = 0;
+    o->camera_model = SFMBA_CAMERA_PINHOLE;
 }
 
 int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
@@ -1410,13 +1479,14 @@ int sfmba_jacobian_blocks(sfmba_handle* h, double* jac_cam, double* jac_pt) {
         refresh_dev(h);
         const size_t n = (size_t)h->n_obs_all;
         DBuf<double> jc, jp;
-        jc.alloc(12 * n); jp.alloc(6 * n);
+        const size_t jw = 2 * (size_t)h->cd;
+        jc.alloc(jw * n); jp.alloc(6 * n);
         if (h->n_obs != h->n_obs_all) {
-            HIP_TRY(hipMemcpyAsync(jc.p, jac_cam, 12 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(jc.p, jac_cam, jw * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(jp.p, jac_pt, 6 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         }
         launch_jacobian_blocks(h->dev, jc.p, jp.p, h->stream);
-        HIP_TRY(hipMemcpyAsync(jac_cam, jc.p, 12 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(jac_cam, jc.p, jw * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(jac_pt, jp.p, 6 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     });
@@ -1429,7 +1499,17 @@ int sfmba_solve(sfmba_handle* h, sfmba_stats* stats) {
 int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) {
     return guarded(h, [&] {
         need_problem(h, "sfmba_get_params");
-        if (camera_params) {
+        if (camera_params && h->model == MODEL_BAL) {
+            std::vector<double> rec((size_t)h->n_cam * 16);
+            HIP_TRY(hipMemcpyAsync(rec.data(), h->cams[h->cur].p, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            for (int64_t c = 0; c < h->n_cam; ++c) {
+                const double* r = rec.data() + 16 * c;
+                double* o = camera_params + 9 * c;
+                vector_of_rotation(r, o);
+                for (int i = 0; i < 6; ++i) o[3 + i] = r[9 + i];
+            }
+        } else if (camera_params) {
             HIP_TRY(hipMemcpyAsync(camera_params, h->cams[h->cur].p, (size_t)h->n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         }
         if (points_3d) {
@@ -1533,16 +1613,18 @@ int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, doubl
     return guarded(h, [&] {
         need_linearized(h, "sfmba_get_blocks");
         if (U || g_cam) {
-            std::vector<double> ug((size_t)h->n_cam * 27);
+            const int cd = h->cd, cv = h->cv;
+            std::vector<double> ug((size_t)h->n_cam * cv);
             HIP_TRY(hipMemcpy(ug.data(), h->UG.p, ug.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (int64_t c = 0; c < h->n_cam; ++c) {
-                const double* u = ug.data() + 27 * c;
+                const double* u = ug.data() + (size_t)cv * c;
                 if (U) {
                     int n = 0;
-                    for (int i = 0; i < 6; ++i)
-                        for (int j = i; j < 6; ++j) { U[36 * c + 6 * i + j] = u[n]; U[36 * c + 6 * j + i] = u[n]; ++n; }
+                    double* o = U + (size_t)cd * cd * c;
+                    for (int i = 0; i < cd; ++i)
+                        for (int j = i; j < cd; ++j) { o[cd * i + j] = u[n]; o[cd * j + i] = u[n]; ++n; }
                 }
-                if (g_cam) for (int i = 0; i < 6; ++i) g_cam[6 * c + i] = u[21 + i];
+                if (g_cam) for (int i = 0; i < cd; ++i) g_cam[(size_t)cd * c + i] = u[cv - cd + i];
             }
         }
         if (V) {
@@ -1567,7 +1649,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y) {
     return guarded(h, [&] {
         need_linearized(h, "sfmba_schur_matvec");
         if (!x || !y) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_schur_matvec: null array");
-        const size_t n = (size_t)h->n_cam * 6;
+        const size_t n = (size_t)h->n_cam * h->cd;
         HIP_TRY(hipMemcpyAsync(h->pz.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (h->explicit_schur) {
             launch_bsr_spmv(h->dev, h->pz.p, h->pq.p, h->stream);
@@ -1583,8 +1665,8 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y) {
 int sfmba_get_reduced(sfmba_handle* h, double* rhs, double* precond_inv) {
     return guarded(h, [&] {
         need_linearized(h, "sfmba_get_reduced");
-        if (rhs) HIP_TRY(hipMemcpy(rhs, h->rhs.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost));
-        if (precond_inv) HIP_TRY(hipMemcpy(precond_inv, h->Minv.p, (size_t)h->n_cam * 36 * sizeof(double), hipMemcpyDeviceToHost));
+        if (rhs) HIP_TRY(hipMemcpy(rhs, h->rhs.p, (size_t)h->n_cam * h->cd * sizeof(double), hipMemcpyDeviceToHost));
+        if (precond_inv) HIP_TRY(hipMemcpy(precond_inv, h->Minv.p, (size_t)h->n_cam * h->cd * h->cd * sizeof(double), hipMemcpyDeviceToHost));
     });
 }
 
@@ -1597,7 +1679,7 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
         dp.alloc((size_t)std::max(h->n_pts, 1) * 3);
         dp.zero(h->stream);                 // points without observations do not move
         phase_trial(h, dp.p);
-        if (step_cam) HIP_TRY(hipMemcpyAsync(step_cam, h->px.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (step_cam) HIP_TRY(hipMemcpyAsync(step_cam, h->px.p, (size_t)h->n_cam * h->cd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         std::vector<double> hdp((size_t)h->n_pts * 3);
         if (step_pt && h->n_pts)
             HIP_TRY(hipMemcpyAsync(hdp.data(), dp.p, hdp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

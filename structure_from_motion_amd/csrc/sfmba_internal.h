@@ -72,7 +72,8 @@ struct Dev {
     int n_pts;            // points owned by this partition
     int n_obs;            // observations of the owned points
     int n_chunks;         // camera-major chunks
-    Intr K;
+    int model;            // CameraModel: record layout of `cams`, tangent size of a camera
+    Intr K;               // pinhole model only
     // static structure
     int n_wtiles;             // wave tiles of the point-major order
     const int* wtile_beg;     // [n_wtiles+1] observation range of each tile: whole points, at most
@@ -88,7 +89,7 @@ struct Dev {
     const int* chunk_beg;     // [n_chunks+1] offsets into cm arrays (chunk q = [beg[q], beg[q+1]))
     const int* cam_chunk_ptr; // [n_cam+1] chunk range of each camera
     // parameters (current and trial)
-    const double2* cams;      // [n_cam][12]
+    const double2* cams;      // [n_cam][12] (pinhole) or [n_cam][16] (BAL)
     const double4* X;         // [n_pts] (x, y, z, pad)
     double2* cams_trial;
     double4* X_trial;
@@ -101,12 +102,13 @@ struct Dev {
     double* Vinv;       // [n_pts][6] (V + lambda D)^-1
     double4* s;         // [n_pts] work vector of the matvec / V*^-1 g_p
     double4* s0;        // [n_pts] V*^-1 g_p
-    double* chunk_part; // [n_chunks][27]
-    double* UG;         // [n_cam][27]: 21 packed upper J_c'J_c | 6 g_c (all ranks' sum)
-    double* T;          // [n_cam][27]: 21 sum W V*^-1 W' | 6 sum W V*^-1 g_p
-    double* Minv;       // [n_cam][36] inverse of the block-Jacobi blocks
-    double* rhs;        // [n_cam][6]
-    // PCG vectors, [n_cam][6]
+    // camera-sized arrays: ND = 6 (pinhole) or 9 (BAL) tangent numbers, NU = ND (ND + 1) / 2
+    double* chunk_part; // [n_chunks][NU + ND]
+    double* UG;         // [n_cam][NU + ND]: packed upper J_c'J_c | g_c (all ranks' sum)
+    double* T;          // [n_cam][NU + ND]: sum W V*^-1 W' | sum W V*^-1 g_p
+    double* Minv;       // [n_cam][ND * ND] inverse of the block-Jacobi blocks
+    double* rhs;        // [n_cam][ND]
+    // PCG vectors, [n_cam][ND]
     double* px; double* pr; double* pz; double* pq; double* qS;
     double* pp[2];      // search direction, double-buffered by iteration parity
     PcgState* pcg;      // [2], double-buffered by iteration parity
@@ -130,6 +132,11 @@ struct Dev {
     double* scal_part;  // [SLOT_COUNT][kMaxScalBlocks]
     double* scalars;    // [SLOT_COUNT]
 };
+
+inline int cam_dim(const Dev& d) { return d.model == MODEL_BAL ? Bal::ND : Pinhole::ND; }
+inline int cam_dim(int model) { return model == MODEL_BAL ? Bal::ND : Pinhole::ND; }
+inline int cam_sums(int model) { return model == MODEL_BAL ? Bal::NV : Pinhole::NV; }      // packed upper + gradient
+inline int cam_words(int model) { return model == MODEL_BAL ? Bal::CW : Pinhole::CW; }     // double2 per camera record
 
 // ---- launch wrappers (sfmba_kernels.hip) -------------------------------------------------
 void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);

@@ -24,35 +24,59 @@ __device__ __forceinline__ void put_partial(const Dev& d, int slot, double v) {
     d.scal_part[(size_t)slot * kMaxScalBlocks + blockIdx.x] = v;
 }
 
+// Every observation kernel is a template over the camera model (sfmba_device.h) and launched for
+// the model of the problem.
+#define SFMBA_LAUNCH(d, KERNEL, grid, st, ...)                                                        \
+    do {                                                                                              \
+        if ((d).model == MODEL_BAL) hipLaunchKernelGGL((KERNEL<Bal>), grid, dim3(kBlock), 0, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((KERNEL<Pinhole>), grid, dim3(kBlock), 0, st, __VA_ARGS__);          \
+    } while (0)
+
+// The ND tangent numbers of camera c out of a camera-sized vector.
+template <int ND>
+__device__ __forceinline__ void load_tangent(const double* __restrict__ x, int c, double (&dd)[ND]) {
+    if constexpr (ND % 2 == 0) {
+        const double2* xc = reinterpret_cast<const double2*>(x + ND * (size_t)c);
+#pragma unroll
+        for (int i = 0; i < ND / 2; ++i) { const double2 v = xc[i]; dd[2 * i] = v.x; dd[2 * i + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dd[i] = x[ND * (size_t)c + i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fun() parity: residuals in the caller's observation order.
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_residuals(Dev d, double* __restrict__ out) {
     int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= d.n_obs) return;
     double4 X = d.X[d.pm_pt[j]];
-    Cam k = load_cam(d.cams, d.pm_cam[j]);
-    Seed s = project_seed(k, X.x, X.y, X.z);
+    const typename M::Cam k = M::load(d.cams, d.pm_cam[j]);
+    const typename M::Obs ob = M::obs(M::seed(k, X.x, X.y, X.z), k, d.K);
     double2 uv = d.pm_uv[j];
     double ru, rv;
-    residual(s, d.K, uv.x, uv.y, ru, rv);
+    M::residual(ob, uv.x, uv.y, ru, rv);
     size_t o = 2 * (size_t)d.pm_orig[j];
     out[o] = ru;
     out[o + 1] = rv;
 }
 
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_jacobian_blocks(Dev d, double* __restrict__ jc_out,
                                                             double* __restrict__ jp_out) {
+    constexpr int ND = M::ND;
     int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= d.n_obs) return;
     double4 X = d.X[d.pm_pt[j]];
-    Cam k = load_cam(d.cams, d.pm_cam[j]);
-    Seed s = project_seed(k, X.x, X.y, X.z);
-    double jc[12], a[3], b[3];
-    jac_cam(s, d.K, jc);
-    jac_pt(s, d.K, k.q, a, b);
+    const typename M::Cam k = M::load(d.cams, d.pm_cam[j]);
+    const typename M::Obs ob = M::obs(M::seed(k, X.x, X.y, X.z), k, d.K);
+    double jc[2 * ND], a[3], b[3];
+    M::jac_cam(ob, jc);
+    M::jac_pt(ob, k.q, a, b);
     size_t o = (size_t)d.pm_orig[j];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) jc_out[12 * o + i] = jc[i];
+    for (int i = 0; i < 2 * ND; ++i) jc_out[2 * ND * o + i] = jc[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { jp_out[6 * o + i] = a[i]; jp_out[6 * o + 3 + i] = b[i]; }
 }
@@ -99,7 +123,7 @@ __device__ __forceinline__ void damp_point(const Dev& d, int p, const double* Vi
 // (every other consumer rebuilds them from X and the camera it gathers anyway).
 // With lambda > 0 the writer lane also damps its point: Vinv = (V + lambda clamp(diag V))^-1 and
 // s0 = Vinv g_p, what k_damp_pm would otherwise read V and g_p back for.
-template <bool kStore>
+template <class M, bool kStore>
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
     __shared__ double red[block_reduce_scratch<2>()];
     const int lane = threadIdx.x & 63;
@@ -111,17 +135,18 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
         const int p = d.pm_pt[j];
         key = p;
         const double4 X = d.X[p];
-        const Cam k = load_cam(d.cams, d.pm_cam[j]);
-        const Seed s = project_seed(k, X.x, X.y, X.z);
+        const typename M::Cam k = M::load(d.cams, d.pm_cam[j]);
+        const Seed s = M::seed(k, X.x, X.y, X.z);
+        const typename M::Obs ob = M::obs(s, k, d.K);
         const double2 uv = d.pm_uv[j];
         double ru, rv;
-        residual(s, d.K, uv.x, uv.y, ru, rv);
+        M::residual(ob, uv.x, uv.y, ru, rv);
         if (kStore) {
             d.pm_seed[j] = make_double4(s.x, s.y, s.iz, ru);
             d.pm_rv[j] = rv;
         }
         double a[3], b[3];
-        jac_pt(s, d.K, k.q, a, b);
+        M::jac_pt(ob, k.q, a, b);
         acc[0] += a[0] * a[0] + b[0] * b[0];
         acc[1] += a[0] * a[1] + b[0] * b[1];
         acc[2] += a[0] * a[2] + b[0] * b[2];
@@ -157,9 +182,25 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
     if (threadIdx.x < 2) put_partial(d, SLOT_COST + threadIdx.x, r);
 }
 
+// The NV sums of a chunk, reduced over the wavefront through its LDS tile and written as the
+// chunk's row of chunk_part.
+template <int NV>
+__device__ __forceinline__ void chunk_store(const Dev& d, int q, const double (&acc)[NV], double* lds, int lane) {
+    double tot[(NV + 13) / 14];
+    wave_sum_lds<NV, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);
+    if (lane < 14) {
+        double* o = d.chunk_part + NV * (size_t)q;
+#pragma unroll
+        for (int p = 0; p < (NV + 13) / 14; ++p)
+            if (14 * p + lane < NV) o[14 * p + lane] = tot[p];
+    }
+}
+
 // Linearisation, camera-major half: seeds per observation (camera-major copy) and the chunk
-// partials of U_c (21 packed upper) and g_c (6).
+// partials of U_c (packed upper) and g_c.
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
+    constexpr int ND = M::ND, NU = M::NU, NV = M::NV;
     __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
@@ -167,34 +208,29 @@ __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
     const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
-    Cam cam = load_cam(d.cams, c);
-    double acc[27];
+    const typename M::Cam cam = M::load(d.cams, c);
+    double acc[NV];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         double4 X = d.X[d.cm_pt[k]];
-        Seed s = project_seed(cam, X.x, X.y, X.z);
+        const Seed s = M::seed(cam, X.x, X.y, X.z);
+        const typename M::Obs ob = M::obs(s, cam, d.K);
         double2 uv = d.cm_uv[k];
         double ru, rv;
-        residual(s, d.K, uv.x, uv.y, ru, rv);
+        M::residual(ob, uv.x, uv.y, ru, rv);
         d.cm_sx[k] = s.x; d.cm_sy[k] = s.y; d.cm_siz[k] = s.iz;
-        double jc[12];
-        jac_cam(s, d.K, jc);
+        double jc[2 * ND];
+        M::jac_cam(ob, jc);
         int n = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < ND; ++i)
 #pragma unroll
-            for (int j = i; j < 6; ++j) acc[n++] += jc[i] * jc[j] + jc[6 + i] * jc[6 + j];
+            for (int j = i; j < ND; ++j) acc[n++] += jc[i] * jc[j] + jc[ND + i] * jc[ND + j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += jc[i] * ru + jc[6 + i] * rv;
+        for (int i = 0; i < ND; ++i) acc[NU + i] += jc[i] * ru + jc[ND + i] * rv;
     }
-    double tot[2];
-    wave_sum_lds<27, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);
-    if (lane < 14) {
-        double* o = d.chunk_part + 27 * (size_t)q;
-        o[lane] = tot[0];
-        if (lane < 13) o[14 + lane] = tot[1];
-    }
+    chunk_store<NV>(d, q, acc, lds, lane);
 }
 
 // out[c][v] = sum over the chunks of camera c of chunk_part[q][v], fixed order.
@@ -216,9 +252,11 @@ __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
     damp_point(d, p, d.V + 6 * (size_t)p, d.gp + 4 * (size_t)p, lambda);
 }
 
-// Camera-major: chunk partials of T_c = sum W Vinv W' (21 packed upper) and sum W s0 (6),
-// W = Jc' Jp (6x3), formed as Jc' (Jp Vinv Jp') Jc without the 6x3 intermediates.
+// Camera-major: chunk partials of T_c = sum W Vinv W' (packed upper) and sum W s0,
+// W = Jc' Jp (ND x 3), formed as Jc' (Jp Vinv Jp') Jc without the ND x 3 intermediates.
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
+    constexpr int ND = M::ND, NU = M::NU, NV = M::NV;
     __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
@@ -226,19 +264,20 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
     const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
-    Cam cam = load_cam(d.cams, c);
-    double acc[27];
+    const typename M::Cam cam = M::load(d.cams, c);
+    double acc[NV];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         const int p = d.cm_pt[k];
         Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
+        const typename M::Obs ob = M::obs(s, cam, d.K);
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
         double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
         double4 s0 = d.s0[p];
-        double jc[12], a[3], b[3];
-        jac_cam(s, d.K, jc);
-        jac_pt(s, d.K, cam.q, a, b);
+        double jc[2 * ND], a[3], b[3];
+        M::jac_cam(ob, jc);
+        M::jac_pt(ob, cam.q, a, b);
         // M = Jp Vinv Jp' (2x2 symmetric), then Jc' M Jc (upper triangle)
         const double ta0 = v01.x * a[0] + v01.y * a[1] + v23.x * a[2];
         const double ta1 = v01.y * a[0] + v23.y * a[1] + v45.x * a[2];
@@ -251,74 +290,65 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
         const double m11 = b[0] * tb0 + b[1] * tb1 + b[2] * tb2;
         int n = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double l0 = jc[i] * m00 + jc[6 + i] * m01;
-            const double l1 = jc[i] * m01 + jc[6 + i] * m11;
+        for (int i = 0; i < ND; ++i) {
+            const double l0 = jc[i] * m00 + jc[ND + i] * m01;
+            const double l1 = jc[i] * m01 + jc[ND + i] * m11;
 #pragma unroll
-            for (int j = i; j < 6; ++j) acc[n++] += l0 * jc[j] + l1 * jc[6 + j];
+            for (int j = i; j < ND; ++j) acc[n++] += l0 * jc[j] + l1 * jc[ND + j];
         }
         // Jc' (Jp (Vinv g_p)): the right-hand-side contribution
         const double w0 = a[0] * s0.x + a[1] * s0.y + a[2] * s0.z;
         const double w1 = b[0] * s0.x + b[1] * s0.y + b[2] * s0.z;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += jc[i] * w0 + jc[6 + i] * w1;
+        for (int i = 0; i < ND; ++i) acc[NU + i] += jc[i] * w0 + jc[ND + i] * w1;
     }
-    double tot[2];
-    wave_sum_lds<27, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);
-    if (lane < 14) {
-        double* o = d.chunk_part + 27 * (size_t)q;
-        o[lane] = tot[0];
-        if (lane < 13) o[14 + lane] = tot[1];
-    }
+    chunk_store<NV>(d, q, acc, lds, lane);
 }
 
-// Per camera: Minv = (U + lambda D - T)^-1, rhs = -g_c + T[21..26]; gradient max.
+// Per camera: Minv = (U + lambda D - T)^-1, rhs = -g_c + T[NU..].
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_precond(Dev d, double lambda) {
-    __shared__ double red[16];
+    constexpr int ND = M::ND, NU = M::NU, NV = M::NV;
     int c = blockIdx.x * kBlock + threadIdx.x;
-    double gmax = 0.0;
     if (c < d.n_cam) {
-        const double* U = d.UG + 27 * (size_t)c;
-        const double* T = d.T + 27 * (size_t)c;
-        double A[6][6], Ai[6][6], Ud[6];
+        const double* U = d.UG + NV * (size_t)c;
+        const double* T = d.T + NV * (size_t)c;
+        double A[ND][ND], Ai[ND][ND], Ud[ND];
         int n = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < ND; ++i)
 #pragma unroll
-            for (int j = i; j < 6; ++j) {
+            for (int j = i; j < ND; ++j) {
                 double v = U[n] - T[n];
                 if (i == j) { Ud[i] = U[n] + lambda * fmin(fmax(U[n], 1e-6), 1e32); v = Ud[i] - T[n]; }
                 A[i][j] = v; A[j][i] = v;
                 ++n;
             }
-        bool ok = spd6_inverse(A, Ai);
-        double* o = d.Minv + 36 * (size_t)c;
+        bool ok = spd_inverse(A, Ai);
+        double* o = d.Minv + ND * ND * (size_t)c;
         if (ok) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < ND; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) o[6 * i + j] = Ai[i][j];
+                for (int j = 0; j < ND; ++j) o[ND * i + j] = Ai[i][j];
         } else {   // fall back to the damped diagonal of U
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < ND; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) o[6 * i + j] = (i == j) ? 1.0 / Ud[i] : 0.0;
+                for (int j = 0; j < ND; ++j) o[ND * i + j] = (i == j) ? 1.0 / Ud[i] : 0.0;
         }
-        const double* g = d.UG + 27 * (size_t)c + 21;
-        double* r = d.rhs + 6 * (size_t)c;
+        const double* g = d.UG + NV * (size_t)c + NU;
+        double* r = d.rhs + ND * (size_t)c;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            r[i] = -g[i] + T[21 + i];
-            gmax = fmax(gmax, fabs(g[i]));
-        }
+        for (int i = 0; i < ND; ++i) r[i] = -g[i] + T[NU + i];
     }
-    (void)gmax;
-    (void)red;
 }
 
 // ------------------------------------------------------------------------------------------
 // Schur matvec, point-major half: s_p = Vinv_p * sum_o Jp' (Jc x_c).
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restrict__ x, const PcgState* __restrict__ state) {
+    constexpr int ND = M::ND;
     if (state && state->done) return;
     const int lane = threadIdx.x & 63;
     const Tile t = wave_tile(d);
@@ -329,15 +359,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restr
         const int c = d.pm_cam[j];
         const double4 sd = d.pm_seed[j];
         Seed s; s.x = sd.x; s.y = sd.y; s.iz = sd.z;
-        const double2* xc = reinterpret_cast<const double2*>(x + 6 * (size_t)c);
-        const double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
-        const double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
+        double dd[ND];
+        load_tangent<ND>(x, c, dd);
+        const typename M::Cam k = M::load_rot(d.cams, c);
+        const typename M::Obs ob = M::obs(s, k, d.K);
         double w0, w1;
-        jc_times(s, d.K, dd, w0, w1);
-        const double2* cq = d.cams + 6 * (size_t)c;
-        const double2 q01 = cq[0], q23 = cq[1], q45 = cq[2], q67 = cq[3], q8 = cq[4];
-        const double Q[9] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y, q8.x};
-        jpT_times_acc(s, d.K, Q, w0, w1, e);
+        M::jc_times(ob, dd, w0, w1);
+        M::jpT_times_acc(ob, k.q, w0, w1, e);
     }
     bool writer;
     if (t.is_long) {
@@ -361,8 +389,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restr
     }
 }
 
-// Schur matvec, camera-major half: chunk partials of sum_o Jc' (Jp s_p)  (6 values).
+// Schur matvec, camera-major half: chunk partials of sum_o Jc' (Jp s_p)  (ND values).
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __restrict__ svec, const PcgState* __restrict__ state) {
+    constexpr int ND = M::ND;
     if (state && state->done) return;
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
@@ -370,22 +400,25 @@ __global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __rest
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
     const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
-    Cam cam = load_cam(d.cams, c);
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const typename M::Cam cam = M::load(d.cams, c);
+    double acc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) acc[i] = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
+        const typename M::Obs ob = M::obs(s, cam, d.K);
         double4 sp = svec[d.cm_pt[k]];
         double dd[3] = {sp.x, sp.y, sp.z};
         double w0, w1;
-        jp_times(s, d.K, cam.q, dd, w0, w1);
-        jcT_times_acc(s, d.K, w0, w1, acc);
+        M::jp_times(ob, cam.q, dd, w0, w1);
+        M::jcT_times_acc(ob, w0, w1, acc);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] = wave_sum(acc[i]);
+    for (int i = 0; i < ND; ++i) acc[i] = wave_sum(acc[i]);
     if (lane == 0) {
-        double* o = d.chunk_part + 6 * (size_t)q;
+        double* o = d.chunk_part + ND * (size_t)q;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) o[i] = acc[i];
+        for (int i = 0; i < ND; ++i) o[i] = acc[i];
     }
 }
 
@@ -393,16 +426,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __rest
 // Small dense helpers for the camera-sized vectors (the PCG kernels live in sfmba_pcg.hip).
 
 // y = U* x - qS  (diagnostic: one application of the reduced operator).
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __restrict__ x,
                                                         double lambda, double* __restrict__ y) {
+    constexpr int ND = M::ND;
     int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= d.n_cam) return;
-    double p[6], q[6];
+    double p[ND], q[ND];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) p[i] = x[6 * (size_t)c + i];
-    ustar_times(d.UG + 27 * (size_t)c, lambda, p, q);
+    for (int i = 0; i < ND; ++i) p[i] = x[ND * (size_t)c + i];
+    ustar_times<ND>(d.UG + M::NV * (size_t)c, lambda, p, q);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) y[6 * (size_t)c + i] = q[i] - d.qS[6 * (size_t)c + i];
+    for (int i = 0; i < ND; ++i) y[ND * (size_t)c + i] = q[i] - d.qS[ND * (size_t)c + i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -411,30 +446,33 @@ __global__ __launch_bounds__(kBlock) void k_schur_apply(Dev d, const double* __r
 // point (X_trial with the retracted cameras, which k_cam_update must have written): every lane
 // holds its observation, its point's step and gathers its camera anyway.  Seeds and residuals at
 // the linearisation point are rebuilt from X and the camera rather than read back.
-struct BackObs { Seed s; double ru, rv, w0, w1; Cam k; double2 uv; int c; };
-__device__ __forceinline__ BackObs back_load(const Dev& d, const double* __restrict__ dc, int j, const double4& X) {
-    BackObs o;
+template <class M>
+struct BackObs { typename M::Obs s; double ru, rv, w0, w1; typename M::Cam k; double2 uv; int c; };
+template <class M>
+__device__ __forceinline__ BackObs<M> back_load(const Dev& d, const double* __restrict__ dc, int j, const double4& X) {
+    BackObs<M> o;
     o.c = d.pm_cam[j];
     o.uv = d.pm_uv[j];
-    o.k = load_cam(d.cams, o.c);
-    o.s = project_seed(o.k, X.x, X.y, X.z);
-    residual(o.s, d.K, o.uv.x, o.uv.y, o.ru, o.rv);
-    const double2* xc = reinterpret_cast<const double2*>(dc + 6 * (size_t)o.c);
-    const double2 x01 = xc[0], x23 = xc[1], x45 = xc[2];
-    const double dd[6] = {x01.x, x01.y, x23.x, x23.y, x45.x, x45.y};
-    jc_times(o.s, d.K, dd, o.w0, o.w1);
+    o.k = M::load(d.cams, o.c);
+    o.s = M::obs(M::seed(o.k, X.x, X.y, X.z), o.k, d.K);
+    M::residual(o.s, o.uv.x, o.uv.y, o.ru, o.rv);
+    double dd[M::ND];
+    load_tangent<M::ND>(dc, o.c, dd);
+    M::jc_times(o.s, dd, o.w0, o.w1);
     return o;
 }
 // squared residual of observation o at the trial point; non-finite values are counted instead
-__device__ __forceinline__ void trial_cost(const Dev& d, const BackObs& o, const Cam& kt, const double4& X, const double* dp,
+template <class M>
+__device__ __forceinline__ void trial_cost(const Dev& d, const BackObs<M>& o, const typename M::Cam& kt, const double4& X, const double* dp,
                                            double& cost, double& bad) {
-    const Seed st = project_seed(kt, X.x + dp[0], X.y + dp[1], X.z + dp[2]);
+    const typename M::Obs st = M::obs(M::seed(kt, X.x + dp[0], X.y + dp[1], X.z + dp[2]), kt, d.K);
     double ru, rv;
-    residual(st, d.K, o.uv.x, o.uv.y, ru, rv);
+    M::residual(st, o.uv.x, o.uv.y, ru, rv);
     const double e = ru * ru + rv * rv;
     if (isfinite(e)) cost += e; else bad += 1.0;
 }
 
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
                                                     double* __restrict__ dp_out) {
     __shared__ double red[block_reduce_scratch<5>()];
@@ -443,13 +481,13 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     double model = 0.0, step2 = 0.0, x2 = 0.0, trial = 0.0, bad = 0.0;
     double e[3] = {0, 0, 0};
     int key = -1 - lane;
-    BackObs o{};
+    BackObs<M> o{};
     double4 X = make_double4(0.0, 0.0, 0.0, 0.0);
     // everything the lane will need after the segmented sum is requested up front, so that the
     // scan does not sit between two rounds of memory latency
     double4 g = make_double4(0.0, 0.0, 0.0, 0.0);
     double2 v01 = make_double2(0.0, 0.0), v23 = v01, v45 = v01;
-    Cam kt{};
+    typename M::Cam kt{};
     for (int j = t.beg + lane; j < t.end; j += 64) {
         key = d.pm_pt[j];
         X = d.X[key];
@@ -458,9 +496,9 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
             const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
             v01 = vi[0]; v23 = vi[1]; v45 = vi[2];
         }
-        o = back_load(d, dc, j, X);
-        if (!t.is_long) kt = load_cam(d.cams_trial, o.c);
-        jpT_times_acc(o.s, d.K, o.k.q, o.w0, o.w1, e);
+        o = back_load<M>(d, dc, j, X);
+        if (!t.is_long) kt = M::load(d.cams_trial, o.c);
+        M::jpT_times_acc(o.s, o.k.q, o.w0, o.w1, e);
     }
     bool writer;
     if (t.is_long) {
@@ -496,20 +534,20 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     }
     if (t.is_long) {
         for (int j = t.beg + lane; j < t.end; j += 64) {
-            const BackObs b = back_load(d, dc, j, X);
-            const Cam kt = load_cam(d.cams_trial, b.c);
+            const BackObs<M> b = back_load<M>(d, dc, j, X);
+            const typename M::Cam kt = M::load(d.cams_trial, b.c);
             double u0, u1;
-            jp_times(b.s, d.K, b.k.q, dp, u0, u1);
+            M::jp_times(b.s, b.k.q, dp, u0, u1);
             const double l0 = b.ru + b.w0 + u0, l1 = b.rv + b.w1 + u1;
             model += l0 * l0 + l1 * l1;
-            trial_cost(d, b, kt, X, dp, trial, bad);
+            trial_cost<M>(d, b, kt, X, dp, trial, bad);
         }
     } else if (key >= 0) {
         double u0, u1;
-        jp_times(o.s, d.K, o.k.q, dp, u0, u1);
+        M::jp_times(o.s, o.k.q, dp, u0, u1);
         const double l0 = o.ru + o.w0 + u0, l1 = o.rv + o.w1 + u1;
         model = l0 * l0 + l1 * l1;
-        trial_cost(d, o, kt, X, dp, trial, bad);
+        trial_cost<M>(d, o, kt, X, dp, trial, bad);
     }
     static_assert(SLOT_STEP2_PT == SLOT_MODEL + 1 && SLOT_X2_PT == SLOT_MODEL + 2 && SLOT_TRIAL == SLOT_MODEL + 3 &&
                   SLOT_NONFINITE == SLOT_MODEL + 4, "slot order");
@@ -519,29 +557,18 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
 }
 
 // Camera retraction: Q' = exp([dw]x) Q, t' = exp([dw]x) t + dt.
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __restrict__ dc) {
+    constexpr int ND = M::ND;
     __shared__ double red[16];
     int c = blockIdx.x * kBlock + threadIdx.x;
     double step2 = 0.0, x2 = 0.0;
     if (c < d.n_cam) {
-        Cam k = load_cam(d.cams, c);
-        double w[6];
+        const typename M::Cam k = M::load(d.cams, c);
+        double w[ND];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { w[i] = dc[6 * (size_t)c + i]; step2 += w[i] * w[i]; }
-        double E[9];
-        so3_exp(w, E);
-        double o[12];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                o[3 * i + j] = E[3 * i] * k.q[j] + E[3 * i + 1] * k.q[3 + j] + E[3 * i + 2] * k.q[6 + j];
-            o[9 + i] = E[3 * i] * k.t[0] + E[3 * i + 1] * k.t[1] + E[3 * i + 2] * k.t[2] + w[3 + i];
-        }
-        double2* dst = d.cams_trial + 6 * (size_t)c;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dst[i] = make_double2(o[2 * i], o[2 * i + 1]);
-        x2 = 3.0 + k.t[0] * k.t[0] + k.t[1] * k.t[1] + k.t[2] * k.t[2];
+        for (int i = 0; i < ND; ++i) { w[i] = dc[ND * (size_t)c + i]; step2 += w[i] * w[i]; }
+        M::store(d.cams_trial, c, M::retract(k, w, x2));
     }
     double a = block_sum(step2, red);
     double b = block_sum(x2, red);
@@ -563,6 +590,7 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
 // Per-camera sum of reprojection errors |projection - observation| at the current estimate,
 // camera-major: chunk partials (sum, count).  The per-view quantity the reference prints after
 // every bundle adjustment (/root/reference/view.py:103-119, utils.py:337-352).
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_reproj_cm(Dev d) {
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
@@ -570,14 +598,14 @@ __global__ __launch_bounds__(kBlock) void k_reproj_cm(Dev d) {
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
     const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
-    const Cam cam = load_cam(d.cams, c);
+    const typename M::Cam cam = M::load(d.cams, c);
     double sum = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         const double4 X = d.X[d.cm_pt[k]];
-        const Seed s = project_seed(cam, X.x, X.y, X.z);
+        const typename M::Obs ob = M::obs(M::seed(cam, X.x, X.y, X.z), cam, d.K);
         const double2 uv = d.cm_uv[k];
         double ru, rv;
-        residual(s, d.K, uv.x, uv.y, ru, rv);
+        M::residual(ob, uv.x, uv.y, ru, rv);
         sum += sqrt(ru * ru + rv * rv);
     }
     sum = wave_sum(sum);
@@ -587,22 +615,24 @@ __global__ __launch_bounds__(kBlock) void k_reproj_cm(Dev d) {
     }
 }
 void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st) {
-    if (d.n_chunks > 0) hipLaunchKernelGGL(k_reproj_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d);
+    if (d.n_chunks > 0) SFMBA_LAUNCH(d, k_reproj_cm, dim3(blocks_chunk(d)), st, d);
     launch_chunk_reduce(d, 2, out2, st);
 }
 
 // max |g_c| over the cameras (after the all-reduce of UG).
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_gmax_cam(Dev d) {
+    constexpr int ND = M::ND;
     __shared__ double red[16];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     double g = 0.0;
-    if (i < d.n_cam * 6) g = fabs(d.UG[27 * (size_t)(i / 6) + 21 + (i % 6)]);
+    if (i < d.n_cam * ND) g = fabs(d.UG[M::NV * (size_t)(i / ND) + M::NU + (i % ND)]);
     const double m = block_max(g, red);
     if (threadIdx.x == 0) put_partial(d, SLOT_GMAX_CAM, m);
 }
 void launch_gmax_cam(const Dev& d, hipStream_t st) {
-    const int nb = cdiv(d.n_cam * 6, kBlock);
-    hipLaunchKernelGGL(k_gmax_cam, dim3(nb), dim3(kBlock), 0, st, d);
+    const int nb = cdiv(d.n_cam * cam_dim(d), kBlock);
+    SFMBA_LAUNCH(d, k_gmax_cam, dim3(nb), st, d);
     hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, nb, 1u);
 }
 
@@ -623,23 +653,24 @@ int blocks_cam(const Dev& d) { return cdiv(d.n_cam, kBlock); }
 
 void launch_residuals(const Dev& d, double* out, hipStream_t st) {
     if (d.n_obs == 0) return;
-    hipLaunchKernelGGL(k_residuals, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, out);
+    SFMBA_LAUNCH(d, k_residuals, dim3(cdiv(d.n_obs, kBlock)), st, d, out);
 }
 void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st) {
     if (d.n_obs == 0) return;
-    hipLaunchKernelGGL(k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), dim3(kBlock), 0, st, d, jc, jp);
+    SFMBA_LAUNCH(d, k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), st, d, jc, jp);
 }
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st) {
     const int nb = blocks_wtile(d);
     if (nb > 0) {
-        if (store_seeds) hipLaunchKernelGGL(k_lin_pm<true>, dim3(nb), dim3(kBlock), 0, st, d, lambda);
-        else hipLaunchKernelGGL(k_lin_pm<false>, dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        else hipLaunchKernelGGL((k_lin_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
     }
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
 }
 void launch_lin_cm(const Dev& d, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    hipLaunchKernelGGL(k_lin_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d);
+    SFMBA_LAUNCH(d, k_lin_cm, dim3(blocks_chunk(d)), st, d);
 }
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_chunk_reduce, dim3(cdiv(d.n_cam * nvals, kBlock)), dim3(kBlock), 0, st, d, nvals, out);
@@ -650,29 +681,29 @@ void launch_damp_pm(const Dev& d, double lambda, hipStream_t st) {
 }
 void launch_sdiag_cm(const Dev& d, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    hipLaunchKernelGGL(k_sdiag_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d);
+    SFMBA_LAUNCH(d, k_sdiag_cm, dim3(blocks_chunk(d)), st, d);
 }
 void launch_precond(const Dev& d, double lambda, hipStream_t st) {
-    hipLaunchKernelGGL(k_precond, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda);
+    SFMBA_LAUNCH(d, k_precond, dim3(blocks_cam(d)), st, d, lambda);
 }
 void launch_spmv_pm(const Dev& d, const double* x, const PcgState* state, hipStream_t st) {
     if (d.n_wtiles == 0) return;
-    hipLaunchKernelGGL(k_spmv_pm, dim3(blocks_wtile(d)), dim3(kBlock), 0, st, d, x, state);
+    SFMBA_LAUNCH(d, k_spmv_pm, dim3(blocks_wtile(d)), st, d, x, state);
 }
 void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    hipLaunchKernelGGL(k_spmv_cm, dim3(blocks_chunk(d)), dim3(kBlock), 0, st, d, svec, state);
+    SFMBA_LAUNCH(d, k_spmv_cm, dim3(blocks_chunk(d)), st, d, svec, state);
 }
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st) {
-    hipLaunchKernelGGL(k_schur_apply, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, x, lambda, y);
+    SFMBA_LAUNCH(d, k_schur_apply, dim3(blocks_cam(d)), st, d, x, lambda, y);
 }
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st) {
     const int nb = blocks_wtile(d);
-    if (nb > 0) hipLaunchKernelGGL(k_back_pm, dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
+    if (nb > 0) SFMBA_LAUNCH(d, k_back_pm, dim3(nb), st, d, dc, dp_out);
     hipLaunchKernelGGL(k_scal_finalize, dim3(5), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u);     // MODEL .. NONFINITE
 }
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st) {
-    hipLaunchKernelGGL(k_cam_update, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, dc);
+    SFMBA_LAUNCH(d, k_cam_update, dim3(blocks_cam(d)), st, d, dc);
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_STEP2_CAM, blocks_cam(d), 0u);
 }
 

@@ -22,10 +22,11 @@ namespace sfmba {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-constexpr int kCamsPerUpdateBlock = 42;      // 42 cameras x 6 rows = 252 of 256 threads
+// thread = (camera, row) in the vector kernels: 42 cameras x 6 rows (28 x 9) = 252 of 256 threads
+template <int ND> constexpr int cams_per_update_block() { return kBlock / ND; }
 constexpr int kCamsPerSpmvBlock = kBlock / 64;   // one wavefront per camera row
 
-int pcg_update_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerUpdateBlock); }
+int pcg_update_blocks(const Dev& d) { return cdiv(d.n_cam, kBlock / cam_dim(d)); }
 int pcg_spmv_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerSpmvBlock); }
 
 // Sum of n partials by the whole workgroup, result broadcast to every thread (fixed order).
@@ -41,22 +42,31 @@ __device__ __forceinline__ double block_total(const double* __restrict__ part, i
     return r;
 }
 
+// One row of z = M^-1 r: m is the row of the camera's inverse block, r its ND residual numbers.
+template <int ND>
+__device__ __forceinline__ double precond_row(const double* __restrict__ m, const double* r) {
+    double z = m[0] * r[0];
+#pragma unroll
+    for (int i = 1; i < ND; ++i) z += m[i] * r[i];
+    return z;
+}
+
 // x = 0, r = b, z = M^-1 r, p_old = 0, r'z partials; thread = (camera, row).
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d, double tol, int max_iter) {
+    constexpr int kCams = cams_per_update_block<ND>();
     __shared__ double red[16];
     __shared__ double rs[kBlock];
-    const int local = threadIdx.x / 6, k = threadIdx.x - 6 * local;
-    const int c = blockIdx.x * kCamsPerUpdateBlock + local;
-    const bool act = local < kCamsPerUpdateBlock && c < d.n_cam;
-    const size_t o = 6 * (size_t)c + k;
+    const int local = threadIdx.x / ND, k = threadIdx.x - ND * local;
+    const int c = blockIdx.x * kCams + local;
+    const bool act = local < kCams && c < d.n_cam;
+    const size_t o = ND * (size_t)c + k;
     const double rk = act ? d.rhs[o] : 0.0;
     rs[threadIdx.x] = rk;
     __syncthreads();
     double dot = 0.0;
     if (act) {
-        const double* m = d.Minv + 36 * (size_t)c + 6 * k;
-        const double* r6 = rs + 6 * local;
-        const double z = m[0] * r6[0] + m[1] * r6[1] + m[2] * r6[2] + m[3] * r6[3] + m[4] * r6[4] + m[5] * r6[5];
+        const double z = precond_row<ND>(d.Minv + ND * ND * (size_t)c + ND * k, rs + ND * local);
         d.px[o] = 0.0; d.pr[o] = rk; d.pz[o] = z; d.pp[0][o] = 0.0;
         dot = rk * z;
     }
@@ -73,7 +83,9 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d, double tol, int max_
 // Head of an iteration, executed identically by every workgroup.  Returns false when the
 // iteration must not run; thread 0 of workgroup 0 writes the next state.
 struct Head { bool run; double beta; };
+template <int ND>
 __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch) {
+    constexpr int kCams = cams_per_update_block<ND>();
     const PcgState st = d.pcg[cur];
     Head h;
     h.run = false;
@@ -82,7 +94,7 @@ __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch)
         if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg[cur ^ 1] = st;
         return h;
     }
-    const double rz = block_total(d.dot_part + d.dot_off, (d.n_cam + kCamsPerUpdateBlock - 1) / kCamsPerUpdateBlock, scratch);
+    const double rz = block_total(d.dot_part + d.dot_off, (d.n_cam + kCams - 1) / kCams, scratch);
     PcgState nx = st;
     nx.rz = rz;
     if (st.iter == 0) {
@@ -103,7 +115,7 @@ __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch)
 __global__ __launch_bounds__(kBlock) void k_pcg_spmv_bsr(Dev d, int cur) {
     __shared__ double red[16];
     __shared__ double part[kBlock];
-    const Head h = pcg_head(d, cur, red);
+    const Head h = pcg_head<6>(d, cur, red);
     if (!h.run) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * kCamsPerSpmvBlock + w;
@@ -145,34 +157,36 @@ __global__ __launch_bounds__(kBlock) void k_pcg_spmv_bsr(Dev d, int cur) {
 }
 
 // Implicit mode: head and direction only; thread = camera.
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_pcg_dir(Dev d, int cur) {
     __shared__ double red[16];
-    const Head h = pcg_head(d, cur, red);
+    const Head h = pcg_head<ND>(d, cur, red);
     if (!h.run) return;
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= d.n_cam) return;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const size_t o = 6 * (size_t)c + i;
+    for (int i = 0; i < ND; ++i) {
+        const size_t o = ND * (size_t)c + i;
         d.pp[cur ^ 1][o] = d.pz[o] + h.beta * d.pp[cur][o];
     }
 }
 
 // Implicit mode: q = U* p - qS, p'q partials; thread = camera.
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_pcg_q(Dev d, double lambda, int cur) {
     __shared__ double red[16];
     if (d.pcg[cur ^ 1].done) return;
     const int c = blockIdx.x * kBlock + threadIdx.x;
     double dot = 0.0;
     if (c < d.n_cam) {
-        double p[6], q[6];
+        double p[ND], q[ND];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) p[i] = d.pp[cur ^ 1][6 * (size_t)c + i];
-        ustar_times(d.UG + 27 * (size_t)c, lambda, p, q);
+        for (int i = 0; i < ND; ++i) p[i] = d.pp[cur ^ 1][ND * (size_t)c + i];
+        ustar_times<ND>(d.UG + (ND * (ND + 1) / 2 + ND) * (size_t)c, lambda, p, q);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            q[i] -= d.qS[6 * (size_t)c + i];
-            d.pq[6 * (size_t)c + i] = q[i];
+        for (int i = 0; i < ND; ++i) {
+            q[i] -= d.qS[ND * (size_t)c + i];
+            d.pq[ND * (size_t)c + i] = q[i];
             dot += p[i] * q[i];
         }
     }
@@ -181,17 +195,19 @@ __global__ __launch_bounds__(kBlock) void k_pcg_q(Dev d, double lambda, int cur)
 }
 
 // alpha = rz / p'q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; r'z partials.  thread = (camera, row).
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_parts) {
+    constexpr int kCams = cams_per_update_block<ND>();
     __shared__ double red[16];
     __shared__ double rs[kBlock];
     const PcgState st = d.pcg[cur ^ 1];
     if (st.done) return;
     const double pq = block_total(d.dot_part, n_pq_parts, red);
     const double alpha = st.rz / pq;
-    const int local = threadIdx.x / 6, k = threadIdx.x - 6 * local;
-    const int c = blockIdx.x * kCamsPerUpdateBlock + local;
-    const bool act = local < kCamsPerUpdateBlock && c < d.n_cam;
-    const size_t o = 6 * (size_t)c + k;
+    const int local = threadIdx.x / ND, k = threadIdx.x - ND * local;
+    const int c = blockIdx.x * kCams + local;
+    const bool act = local < kCams && c < d.n_cam;
+    const size_t o = ND * (size_t)c + k;
     double rk = 0.0;
     if (act) {
         d.px[o] += alpha * d.pp[cur ^ 1][o];
@@ -202,9 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_
     __syncthreads();
     double dot = 0.0;
     if (act) {
-        const double* m = d.Minv + 36 * (size_t)c + 6 * k;
-        const double* r6 = rs + 6 * local;
-        const double z = m[0] * r6[0] + m[1] * r6[1] + m[2] * r6[2] + m[3] * r6[3] + m[4] * r6[4] + m[5] * r6[5];
+        const double z = precond_row<ND>(d.Minv + ND * ND * (size_t)c + ND * k, rs + ND * local);
         d.pz[o] = z;
         dot = rk * z;
     }
@@ -678,19 +692,23 @@ hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, bool cooperative, hip
 }
 
 void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_init, dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_init<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter);
+    else hipLaunchKernelGGL((k_pcg_init<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter);
 }
 void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st) {
     hipLaunchKernelGGL(k_pcg_spmv_bsr, dim3(pcg_spmv_blocks(d)), dim3(kBlock), 0, st, d, cur);
 }
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_dir, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_dir<Bal::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
+    else hipLaunchKernelGGL((k_pcg_dir<Pinhole::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);
 }
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_q, dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_q<Bal::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
+    else hipLaunchKernelGGL((k_pcg_q<Pinhole::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
 }
 void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_update, dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_update<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
+    else hipLaunchKernelGGL((k_pcg_update<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
 }
 
 }  // namespace sfmba

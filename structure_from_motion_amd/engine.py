@@ -27,6 +27,10 @@ EXPORTS = (
 
 SOLVER_AUTO, SOLVER_PCG, SOLVER_DENSE = 0, 1, 2
 SCHUR_AUTO, SCHUR_IMPLICIT, SCHUR_EXPLICIT = 0, 1, 2
+CAMERA_PINHOLE, CAMERA_BAL = 0, 1
+# per camera model: numbers per camera in camera_params, tangent numbers per camera
+CAMERA_SHAPES = {CAMERA_PINHOLE: (12, 6), CAMERA_BAL: (9, 9)}
+CAMERA_NAMES = {"pinhole": CAMERA_PINHOLE, "bal": CAMERA_BAL}
 
 TERMINATION_MESSAGES = {   # scipy/optimize/_lsq/least_squares.py:18-25
     -1: "Improper input parameters status returned from `leastsq`",
@@ -46,7 +50,7 @@ class Options(C.Structure):
         ("pcg_max_iter", C.c_int32), ("pcg_batch", C.c_int32), ("linear_solver", C.c_int32), ("schur_mode", C.c_int32),
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
-        ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32),
+        ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32), ("camera_model", C.c_int32),
     ]
 
 
@@ -156,7 +160,16 @@ class Engine:
     def __init__(self, **options):
         self._lib = load_library()
         self._h = C.c_void_p()
+        model = options.get("camera_model", CAMERA_PINHOLE)
+        if isinstance(model, str):
+            if model not in CAMERA_NAMES:
+                raise ValueError(f"unknown camera model {model!r}")
+            options = dict(options, camera_model=CAMERA_NAMES[model])
         self.options = default_options(**options)
+        if self.options.camera_model not in CAMERA_SHAPES:
+            raise ValueError(f"unknown camera model {self.options.camera_model}")
+        # numbers per camera in camera_params / in a camera's tangent space
+        self.cam_params, self.cam_dim = CAMERA_SHAPES[self.options.camera_model]
         rc = self._lib.sfmba_create(C.byref(self.options), C.byref(self._h))
         if rc != 0:
             self._h = C.c_void_p()
@@ -193,14 +206,17 @@ class Engine:
     # -- problem
     def set_problem(self, camera_params, points_3d, camera_indices, point_indices, points_2d, K):
         cp, pts = _f64(camera_params), _f64(points_3d)
-        ci, pi, uv, K = _i64(camera_indices), _i64(point_indices), _f64(points_2d), _f64(K)
-        if cp.ndim != 2 or cp.shape[1] != 12:
-            raise ValueError("camera_params must be (n_cameras, 12)")
+        ci, pi, uv = _i64(camera_indices), _i64(point_indices), _f64(points_2d)
+        if K is None and self.options.camera_model == CAMERA_PINHOLE:
+            raise ValueError("K must be 3x3")
+        K = _f64(K) if K is not None else None
+        if cp.ndim != 2 or cp.shape[1] != self.cam_params:
+            raise ValueError(f"camera_params must be (n_cameras, {self.cam_params})")
         if pts.ndim != 2 or pts.shape[1] != 3:
             raise ValueError("points_3d must be (n_points, 3)")
         if ci.shape != pi.shape or ci.ndim != 1 or uv.shape != (ci.size, 2):
             raise ValueError("camera_indices, point_indices (n_obs,) and points_2d (n_obs, 2) disagree")
-        if K.shape != (3, 3):
+        if K is not None and K.shape != (3, 3):
             raise ValueError("K must be 3x3")
         self.n_cameras, self.n_points, self.n_obs = cp.shape[0], pts.shape[0], ci.size
         ipp = C.POINTER(C.c_int64)
@@ -210,7 +226,7 @@ class Engine:
 
     def set_params(self, camera_params, points_3d):
         cp, pts = _f64(camera_params), _f64(points_3d)
-        if cp.shape != (self.n_cameras, 12) or pts.shape != (self.n_points, 3):
+        if cp.shape != (self.n_cameras, self.cam_params) or pts.shape != (self.n_points, 3):
             raise ValueError("parameter shapes do not match the loaded problem")
         self._check(self._lib.sfmba_set_params(self._h, _dp(cp), _dp(pts)))
 
@@ -218,7 +234,7 @@ class Engine:
         self._check(self._lib.sfmba_reset_params(self._h))
 
     def get_params(self):
-        cp = np.empty((self.n_cameras, 12))
+        cp = np.empty((self.n_cameras, self.cam_params))
         pts = np.zeros((self.n_points, 3))
         self._check(self._lib.sfmba_get_params(self._h, _dp(cp), _dp(pts)))
         return cp, pts
@@ -230,7 +246,7 @@ class Engine:
         return out
 
     def jacobian_blocks(self):
-        jc = np.zeros((self.n_obs, 2, 6))
+        jc = np.zeros((self.n_obs, 2, self.cam_dim))
         jp = np.zeros((self.n_obs, 2, 3))
         self._check(self._lib.sfmba_jacobian_blocks(self._h, _dp(jc), _dp(jp)))
         return jc, jp
@@ -275,24 +291,24 @@ class Engine:
         self._check(self._lib.sfmba_linearize(self._h, float(lam)))
 
     def get_blocks(self):
-        U = np.zeros((self.n_cameras, 6, 6)); gc = np.zeros((self.n_cameras, 6))
+        U = np.zeros((self.n_cameras, self.cam_dim, self.cam_dim)); gc = np.zeros((self.n_cameras, self.cam_dim))
         V = np.zeros((self.n_points, 3, 3)); gp = np.zeros((self.n_points, 3))
         self._check(self._lib.sfmba_get_blocks(self._h, _dp(U), _dp(gc), _dp(V), _dp(gp)))
         return U, gc, V, gp
 
     def schur_matvec(self, x):
-        x = _f64(x).reshape(self.n_cameras, 6)
+        x = _f64(x).reshape(self.n_cameras, self.cam_dim)
         y = np.empty_like(x)
         self._check(self._lib.sfmba_schur_matvec(self._h, _dp(x), _dp(y)))
         return y
 
     def get_reduced(self):
-        rhs = np.empty((self.n_cameras, 6)); Minv = np.empty((self.n_cameras, 6, 6))
+        rhs = np.empty((self.n_cameras, self.cam_dim)); Minv = np.empty((self.n_cameras, self.cam_dim, self.cam_dim))
         self._check(self._lib.sfmba_get_reduced(self._h, _dp(rhs), _dp(Minv)))
         return rhs, Minv
 
     def solve_step(self):
-        dc = np.zeros((self.n_cameras, 6)); dp = np.zeros((self.n_points, 3))
+        dc = np.zeros((self.n_cameras, self.cam_dim)); dp = np.zeros((self.n_points, 3))
         it = C.c_int32(0)
         self._check(self._lib.sfmba_solve_step(self._h, _dp(dc), _dp(dp), C.byref(it)))
         return dc, dp, it.value
