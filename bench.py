@@ -202,7 +202,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{args.shape}-shape synthetic BAL problem (seed {args.seed}"
+            "config": {"workload": (f"{args.shape}-shape synthetic problem, pinhole camera of bundle_adjustment.py (seed {args.seed}"
                                     + (f", scale {args.scale}" if args.scale != 1.0 else "") + "): "
                                     f"{p['n_cameras']} cameras / {p['n_points']} points / {n_obs} observations; "
                                     "one step = one full LM solve (Schur complement + block-Jacobi PCG), "
