@@ -374,9 +374,11 @@ void allreduce(H* h, double* buf, size_t count) {
                 launch_vec_add(buf, g->bufs[r], count, h->stream);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            // (device-to-device copies need not have landed when a blocking hipMemcpy returns: queue
+            // them behind the sums and wait for the stream before the other ranks are released)
             for (int r = 1; r < g->n && e == hipSuccess; ++r)
-                e = hipMemcpy(g->bufs[r], buf, count * sizeof(double), hipMemcpyDeviceToDevice);
+                e = hipMemcpyAsync(g->bufs[r], buf, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             g->failed = e != hipSuccess;
         }
         g->barrier();
