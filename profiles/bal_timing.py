@@ -28,7 +28,7 @@ def gpu_solve(p, repeats=5, **opts):
             best = dt if best is None else min(best, dt)
         prof = None
         if opts.get("profile"):
-            prof = {k: getattr(st, k) for k in ("ms_linearize", "ms_damp", "ms_spmv_pm", "ms_spmv_cm", "ms_pcg_vec", "ms_back")}
+            prof = {k: getattr(st, k) for k in ("ms_linearize", "ms_damp", "ms_schur", "ms_pairs", "ms_bsr", "ms_spmv_pm", "ms_spmv_cm", "ms_pcg_vec", "ms_back", "ms_dense")}
     return dict(setup_seconds=setup, solve_seconds=best, iterations=st.iterations, pcg_iterations=st.pcg_iterations,
                 initial_cost=st.initial_cost, final_cost=st.final_cost, status=st.status,
                 obs_iter_per_s=p["camera_indices"].size * st.iterations / best, family_ms=prof)
@@ -46,6 +46,7 @@ def main():
     venice = syn.make_bal_problem(1778, 993923, 5001946, seed=0)
     out["venice_shape_gpu"] = gpu_solve(venice, repeats=3)
     out["venice_shape_gpu_profiled"] = gpu_solve(venice, repeats=1, profile=1)
+    out["venice_shape_gpu_matrix_free"] = gpu_solve(venice, repeats=2, schur_mode=1)
     print(json.dumps(out, indent=1))
 
 

@@ -267,6 +267,14 @@ struct Pinhole {
         dst[0] = make_double2(k.q[0], k.q[1]); dst[1] = make_double2(k.q[2], k.q[3]); dst[2] = make_double2(k.q[4], k.q[5]);
         dst[3] = make_double2(k.q[6], k.q[7]); dst[4] = make_double2(k.q[8], k.t[0]); dst[5] = make_double2(k.t[1], k.t[2]);
     }
+    // a camera that is the same in every lane, moved into scalar registers (rotation only)
+    static __device__ __forceinline__ Cam uniform_rot(const Cam& k) {
+        Cam u;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u.q[i] = wave_uniform(k.q[i]);
+        u.t[0] = u.t[1] = u.t[2] = 0.0;
+        return u;
+    }
     static __device__ __forceinline__ Seed seed(const Cam& k, double X0, double X1, double X2) { return project_seed(k, X0, X1, X2); }
     static __device__ __forceinline__ Obs obs(const Seed& s, const Cam&, const Intr& K) { return Obs{s, K}; }
     static __device__ __forceinline__ void residual(const Obs& o, double u, double v, double& ru, double& rv) { sfmba::residual(o.s, o.K, u, v, ru, rv); }
@@ -329,6 +337,14 @@ struct Bal {
         dst[0] = make_double2(k.q[0], k.q[1]); dst[1] = make_double2(k.q[2], k.q[3]); dst[2] = make_double2(k.q[4], k.q[5]);
         dst[3] = make_double2(k.q[6], k.q[7]); dst[4] = make_double2(k.q[8], k.t[0]); dst[5] = make_double2(k.t[1], k.t[2]);
         dst[6] = make_double2(k.f, k.k1); dst[7] = make_double2(k.k2, 0.0);
+    }
+    static __device__ __forceinline__ Cam uniform_rot(const Cam& k) {
+        Cam u;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u.q[i] = wave_uniform(k.q[i]);
+        u.t[0] = u.t[1] = u.t[2] = 0.0;
+        u.f = wave_uniform(k.f); u.k1 = wave_uniform(k.k1); u.k2 = wave_uniform(k.k2);
+        return u;
     }
     // no guard against Z == 0: the reference divides (ba_test.py:82) and SciPy then refuses the
     // non-finite residual

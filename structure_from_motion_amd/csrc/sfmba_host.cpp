@@ -434,7 +434,7 @@ void phase_damp(H* h, double lambda) {
     if (h->explicit_schur) {
         // per camera, behind the blocks: T_c = sum W Vinv W' (its own observations: the diagonal
         // block's share) and sum W Vinv g_p (the point part of the right-hand side)
-        double* tpart = h->Bsum.p + (size_t)h->n_ublk * 36;
+        double* tpart = h->Bsum.p + (size_t)h->n_ublk * h->cd * h->cd;
         if (h->damped_lambda != lambda) {
             Scope t(h, F_DAMP);
             launch_damp_pm(h->dev, lambda, h->stream);
@@ -442,7 +442,7 @@ void phase_damp(H* h, double lambda) {
         {
             Scope t(h, F_DAMP);
             launch_sdiag_cm(h->dev, h->stream);
-            launch_chunk_reduce(h->dev, 27, tpart, h->stream);
+            launch_chunk_reduce(h->dev, h->cv, tpart, h->stream);
         }
         {
             Scope t(h, F_SCHUR);
@@ -452,7 +452,7 @@ void phase_damp(H* h, double lambda) {
             }
             launch_block_reduce(h->dev, h->stream);
         }
-        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * 36 + (size_t)h->n_cam * 27);
+        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * h->cd * h->cd + (size_t)h->n_cam * h->cv);
         {
             Scope t(h, F_SCHUR);
             launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
@@ -585,7 +585,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
 // step.  Returns false when a pivot was not positive (caller falls back to PCG).
 bool phase_dense(H* h) {
     Scope t(h, F_DENSE);
-    const int n = h->dense_n, n_real = 6 * (int)h->n_cam;
+    const int n = h->dense_n, n_real = h->cd * (int)h->n_cam;
     h->denseA.zero(h->stream);
     h->dense_fail.zero(h->stream);
     launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
@@ -608,7 +608,7 @@ int phase_linear_solve(H* h, double lambda, bool allow_fused = true) {
     const bool converged = !(st.rz > st.tol2 * st.rz0);
     if (!converged && !h->use_dense && h->dense_allowed && h->explicit_schur) {
         if (h->denseA.n == 0) {
-            h->dense_n = dense_padded(6 * (int)h->n_cam);
+            h->dense_n = dense_padded(h->cd * (int)h->n_cam);
             h->denseA.alloc((size_t)h->dense_n * h->dense_n);
             h->denseLinv.alloc((size_t)h->dense_n * 32);
             h->denseWork.alloc((size_t)h->dense_n * 2);
@@ -902,7 +902,7 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d) {
 }
 
 
-int bsr_blocks_host(int n_cam) { Dev d{}; d.n_cam = n_cam; return bsr_blocks(d); }
+int bsr_blocks_host(int n_cam, int model) { Dev d{}; d.n_cam = n_cam; d.model = model; return bsr_blocks(d); }
 
 // Open-addressing set of 64-bit keys (camera pairs), with a small direct-mapped filter in
 // front: consecutive points mostly repeat the pairs of their neighbours.
@@ -949,19 +949,11 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     if (const char* e = getenv("SFMBA_LINEAR_SOLVER")) lin = atoi(e);
     const int dense_max = h->opt.dense_max_dim > 0 ? h->opt.dense_max_dim : 1536;
     const bool want_dense = lin == SFMBA_SOLVER_DENSE;
-    if (h->model != MODEL_PINHOLE) {
-        // the explicit reduced matrix, its single-launch PCG and the dense factorisation are
-        // written for 6x6 camera blocks: other models use the matrix-free product
-        if (want_dense) fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: not available for this camera model");
-        h->dense_allowed = h->use_dense = h->explicit_schur = false;
-        h->fused_pcg = false;
-        h->n_ublk = h->n_pchunks = h->nnzb = 0;
-        h->n_pairs = 0;
-        return;
-    }
-    h->dense_allowed = lin == SFMBA_SOLVER_AUTO && 6 * (int64_t)n_cam <= dense_max;
-    if (6 * (int64_t)n_cam > 16384 && lin == SFMBA_SOLVER_DENSE)
-        fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)(6 * (int64_t)n_cam));
+    const int64_t n_red = (int64_t)h->cd * n_cam;       // unknowns of the reduced system
+    const size_t nn = (size_t)h->cd * h->cd;
+    h->dense_allowed = lin == SFMBA_SOLVER_AUTO && n_red <= dense_max;
+    if (n_red > 16384 && lin == SFMBA_SOLVER_DENSE)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)n_red);
     h->use_dense = false;
     if (want_dense) mode = 2;          // the dense matrix is filled from the explicit blocks
     h->explicit_schur = false;
@@ -1129,9 +1121,9 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->pchunk_blk.upload(pchunk_blk, st); h->pchunk_beg.upload(pchunk_beg, st);
     h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
     h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);
-    h->pair_part.alloc((size_t)std::max<size_t>(pchunk_blk.size(), 1) * 36);
-    h->Bsum.alloc((size_t)n_ublk * 36 + (size_t)n_cam * 27);     // + the per-camera sums T_c, one collective
-    h->Sfull.alloc((size_t)nnzb * 36);
+    h->pair_part.alloc((size_t)std::max<size_t>(pchunk_blk.size(), 1) * nn);
+    h->Bsum.alloc((size_t)n_ublk * nn + (size_t)n_cam * h->cv);     // + the per-camera sums T_c, one collective
+    h->Sfull.alloc((size_t)nnzb * nn);
     h->Bsum.zero(st); h->Sfull.zero(st);
     HIP_TRY(hipStreamSynchronize(st));
     tr.lap("schur: upload");
@@ -1141,7 +1133,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     int pcg_mode = h->opt.pcg_mode;
     if (const char* e = getenv("SFMBA_PCG_MODE")) pcg_mode = atoi(e);
     h->fused_pcg = false;
-    if (pcg_mode != 1 && !want_dense) {
+    if (pcg_mode != 1 && !want_dense && h->model == MODEL_PINHOLE) {     // (written for 6x6 blocks)
         const int cap = pcg_fused_max_blocks(h->device);
         const int rows = pcg_fused_rows_per_block();
         int blocks = std::min(cap, (n_cam + rows - 1) / rows);
@@ -1176,7 +1168,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         }
     }
     if (want_dense) {
-        h->dense_n = dense_padded(6 * n_cam);
+        h->dense_n = dense_padded((int)n_red);
         h->denseA.alloc((size_t)h->dense_n * h->dense_n);
         h->denseLinv.alloc((size_t)h->dense_n * 32);
         h->denseWork.alloc((size_t)h->dense_n * 2);
@@ -1325,7 +1317,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->UG.zero(h->stream);
     h->Minv.alloc((size_t)n_cam * cd * cd); h->rhs.alloc((size_t)n_cam * cd);
     for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp[0], &h->pp[1], &h->pq, &h->qS}) b->alloc((size_t)n_cam * cd);
-    h->nb_bsr = bsr_blocks_host((int)n_cam);
+    h->nb_bsr = bsr_blocks_host((int)n_cam, h->model);
     {
         Dev t{};
         t.n_cam = (int)n_cam;

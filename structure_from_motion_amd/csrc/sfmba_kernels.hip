@@ -662,7 +662,8 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st) {
     const int nb = blocks_wtile(d);
     if (nb > 0) {
-        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        if (d.model == MODEL_BAL && store_seeds) hipLaunchKernelGGL((k_lin_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        else if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
         else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
         else hipLaunchKernelGGL((k_lin_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
     }

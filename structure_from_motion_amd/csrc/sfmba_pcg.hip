@@ -111,42 +111,51 @@ __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch)
 }
 
 // Explicit mode: head, direction and q = S p in one launch.  One wavefront per camera row:
-// lane = (block slot 0..9, row 0..5); each lane walks every tenth block of the row.
+// lane = (block slot, row of the block) with 64 / ND slots (10 for 6x6 blocks, 7 for 9x9); each
+// lane walks every slot-count-th block of the row.
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_pcg_spmv_bsr(Dev d, int cur) {
+    constexpr int kSlots = 64 / ND, NN = ND * ND;
     __shared__ double red[16];
     __shared__ double part[kBlock];
-    const Head h = pcg_head<6>(d, cur, red);
+    const Head h = pcg_head<ND>(d, cur, red);
     if (!h.run) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * kCamsPerSpmvBlock + w;
-    const int sub = lane / 6, k = lane - 6 * sub;
+    const int sub = lane / ND, k = lane - ND * sub;
     const double* __restrict__ z = d.pz;
     const double* __restrict__ po = d.pp[cur];
     double acc = 0.0;
-    if (c < d.n_cam && sub < 10) {
+    if (c < d.n_cam && sub < kSlots) {
         const int b1 = d.bsr_ptr[c + 1];
-        for (int b = d.bsr_ptr[c] + sub; b < b1; b += 10) {
-            const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
-            const size_t col = 6 * (size_t)d.bsr_col[b];
-            const double2* zv = reinterpret_cast<const double2*>(z + col);
-            const double2* pv = reinterpret_cast<const double2*>(po + col);
-            const double2 s0 = s[0], s1 = s[1], s2 = s[2];
-            const double2 z0 = zv[0], z1 = zv[1], z2 = zv[2];
-            const double2 p0 = pv[0], p1 = pv[1], p2 = pv[2];
-            acc += s0.x * (z0.x + h.beta * p0.x) + s0.y * (z0.y + h.beta * p0.y) +
-                   s1.x * (z1.x + h.beta * p1.x) + s1.y * (z1.y + h.beta * p1.y) +
-                   s2.x * (z2.x + h.beta * p2.x) + s2.y * (z2.y + h.beta * p2.y);
+        for (int b = d.bsr_ptr[c] + sub; b < b1; b += kSlots) {
+            const size_t col = ND * (size_t)d.bsr_col[b];
+            if constexpr (ND == 6) {
+                const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
+                const double2* zv = reinterpret_cast<const double2*>(z + col);
+                const double2* pv = reinterpret_cast<const double2*>(po + col);
+                const double2 s0 = s[0], s1 = s[1], s2 = s[2];
+                const double2 z0 = zv[0], z1 = zv[1], z2 = zv[2];
+                const double2 p0 = pv[0], p1 = pv[1], p2 = pv[2];
+                acc += s0.x * (z0.x + h.beta * p0.x) + s0.y * (z0.y + h.beta * p0.y) +
+                       s1.x * (z1.x + h.beta * p1.x) + s1.y * (z1.y + h.beta * p1.y) +
+                       s2.x * (z2.x + h.beta * p2.x) + s2.y * (z2.y + h.beta * p2.y);
+            } else {
+                const double* s = d.Sfull + NN * (size_t)b + ND * k;
+#pragma unroll
+                for (int i = 0; i < ND; ++i) acc += s[i] * (z[col + i] + h.beta * po[col + i]);
+            }
         }
     }
     part[threadIdx.x] = acc;
     __syncthreads();
     double dot = 0.0;
-    if (c < d.n_cam && lane < 6) {
+    if (c < d.n_cam && lane < ND) {
         const double* pw = part + 64 * w + lane;
         double q = 0.0;
 #pragma unroll
-        for (int s = 0; s < 10; ++s) q += pw[6 * s];
-        const size_t o = 6 * (size_t)c + lane;
+        for (int s = 0; s < kSlots; ++s) q += pw[ND * s];
+        const size_t o = ND * (size_t)c + lane;
         const double pn = z[o] + h.beta * po[o];
         d.pp[cur ^ 1][o] = pn;
         d.pq[o] = q;
@@ -696,7 +705,8 @@ void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
     else hipLaunchKernelGGL((k_pcg_init<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter);
 }
 void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st) {
-    hipLaunchKernelGGL(k_pcg_spmv_bsr, dim3(pcg_spmv_blocks(d)), dim3(kBlock), 0, st, d, cur);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_spmv_bsr<Bal::ND>), dim3(pcg_spmv_blocks(d)), dim3(kBlock), 0, st, d, cur);
+    else hipLaunchKernelGGL((k_pcg_spmv_bsr<Pinhole::ND>), dim3(pcg_spmv_blocks(d)), dim3(kBlock), 0, st, d, cur);
 }
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st) {
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_dir<Bal::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, cur);

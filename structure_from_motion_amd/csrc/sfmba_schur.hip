@@ -21,7 +21,9 @@ namespace sfmba {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
+    constexpr int ND = M::ND, NN = ND * ND;
     __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 20];
     const int lane = threadIdx.x & 63;
     const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
@@ -32,16 +34,11 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
     const int r = __builtin_amdgcn_readfirstlane(d.ublk_r[blk]);
     const int c = __builtin_amdgcn_readfirstlane(d.ublk_c[blk]);
     // both cameras are the same for the whole wavefront: their rotations live in scalar registers
-    double qr[9], qc[9];
-    {
-        const Cam camr = load_cam(d.cams, r);
-        const Cam camc = load_cam(d.cams, c);
+    const typename M::Cam camr = M::uniform_rot(M::load_rot(d.cams, r));
+    const typename M::Cam camc = M::uniform_rot(M::load_rot(d.cams, c));
+    double acc[NN];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { qr[i] = wave_uniform(camr.q[i]); qc[i] = wave_uniform(camc.q[i]); }
-    }
-    double acc[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NN; ++i) acc[i] = 0.0;
     for (int k = k0 + lane; k < k1; k += 64) {
         const int ja = d.pair_a[k], jb = d.pair_b[k], p = d.pair_p[k];
         // seeds from the camera-major arrays: the observations of one camera are sorted by point
@@ -51,9 +48,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
         sb.x = d.cm_sx[jb]; sb.y = d.cm_sy[jb]; sb.iz = d.cm_siz[jb];
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
         const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        const typename M::Obs oa = M::obs(sa, camr, d.K), ob = M::obs(sb, camc, d.K);
         double aa[3], ab[3], ba[3], bb[3];
-        jac_pt(sa, d.K, qr, aa, ab);     // rows of Jp_a
-        jac_pt(sb, d.K, qc, ba, bb);     // rows of Jp_b
+        M::jac_pt(oa, camr.q, aa, ab);     // rows of Jp_a
+        M::jac_pt(ob, camc.q, ba, bb);     // rows of Jp_b
         // t0 = Vinv * ba, t1 = Vinv * bb  (Vinv packed upper: 00 01 02 11 12 22)
         const double t00 = v01.x * ba[0] + v01.y * ba[1] + v23.x * ba[2];
         const double t01 = v01.y * ba[0] + v23.y * ba[1] + v45.x * ba[2];
@@ -66,33 +64,35 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
         const double m01 = aa[0] * t10 + aa[1] * t11 + aa[2] * t12;
         const double m10 = ab[0] * t00 + ab[1] * t01 + ab[2] * t02;
         const double m11 = ab[0] * t10 + ab[1] * t11 + ab[2] * t12;
-        double jca[12], jcb[12];
-        jac_cam(sa, d.K, jca);
-        jac_cam(sb, d.K, jcb);
+        double jca[2 * ND], jcb[2 * ND];
+        M::jac_cam(oa, jca);
+        M::jac_cam(ob, jcb);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double l0 = jca[i] * m00 + jca[6 + i] * m10;
-            const double l1 = jca[i] * m01 + jca[6 + i] * m11;
+        for (int i = 0; i < ND; ++i) {
+            const double l0 = jca[i] * m00 + jca[ND + i] * m10;
+            const double l1 = jca[i] * m01 + jca[ND + i] * m11;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] += l0 * jcb[j] + l1 * jcb[6 + j];
+            for (int j = 0; j < ND; ++j) acc[ND * i + j] += l0 * jcb[j] + l1 * jcb[ND + j];
         }
     }
-    double tot[2];
-    wave_sum_lds<36, 18>(acc, lds + (threadIdx.x >> 6) * (64 * 20), lane, tot);
+    constexpr int kPasses = (NN + 17) / 18;
+    double tot[kPasses];
+    wave_sum_lds<NN, 18>(acc, lds + (threadIdx.x >> 6) * (64 * 20), lane, tot);
     if (lane < 18) {
-        double* o = d.pair_part + 36 * (size_t)q;
-        o[lane] = tot[0];
-        o[18 + lane] = tot[1];
+        double* o = d.pair_part + NN * (size_t)q;
+#pragma unroll
+        for (int p = 0; p < kPasses; ++p)
+            if (18 * p + lane < NN) o[18 * p + lane] = tot[p];
     }
 }
 
 // Bsum[u][e] = sum over the chunks of upper block u, fixed order.
-__global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d) {
+__global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d, int nn) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= d.n_ublk * 36) return;
-    const int u = i / 36, e = i - 36 * u;
+    if (i >= d.n_ublk * nn) return;
+    const int u = i / nn, e = i - nn * u;
     double s = 0.0;
-    for (int q = d.ublk_chunk_ptr[u]; q < d.ublk_chunk_ptr[u + 1]; ++q) s += d.pair_part[36 * (size_t)q + e];
+    for (int q = d.ublk_chunk_ptr[u]; q < d.ublk_chunk_ptr[u + 1]; ++q) s += d.pair_part[nn * (size_t)q + e];
     d.Bsum[i] = s;
 }
 
@@ -103,7 +103,9 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d) {
 // Cholesky factor, the inverse (block-Jacobi preconditioner), the reduced right-hand side
 // rhs = -g_c + sum W Vinv g_p and, for the single-launch PCG, the scaling F = L^-1, bhat = F rhs,
 // the scaled diagonal block F S_cc F' and the armed (all bits set) exchange buffers.
+template <class M>
 __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f) {
+    constexpr int ND = M::ND, NU = M::NU, NV = M::NV, NN = ND * ND;
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (f.F != nullptr) {
         // arm the exchange buffers of the single-launch PCG: every word all bits set
@@ -114,169 +116,194 @@ __global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, co
         for (size_t i = c; i < nd; i += (size_t)gridDim.x * kBlock) dw[i] = ~0ull;
     }
     if (c >= d.n_cam) return;
-    const double* U = d.UG + 27 * (size_t)c;
-    const double* T = tpart + 27 * (size_t)c;          // packed upper sum W Vinv W' | sum W Vinv g_p
-    const double* B = d.Bsum + 36 * (size_t)d.ublk_diag[c];   // pairs of two observations of one point in this camera
-    double S[6][6], A[6][6], Li[6][6], Ai[6][6];
+    const double* U = d.UG + NV * (size_t)c;
+    const double* T = tpart + NV * (size_t)c;          // packed upper sum W Vinv W' | sum W Vinv g_p
+    const double* B = d.Bsum + NN * (size_t)d.ublk_diag[c];   // pairs of two observations of one point in this camera
+    double S[ND][ND], A[ND][ND], Li[ND][ND], Ai[ND][ND];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < ND; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < ND; ++j) {
             const int a = i < j ? i : j, b = i < j ? j : i;
-            double uv = U[upidx(6, a, b)];
+            double uv = U[upidx(ND, a, b)];
             if (i == j) uv += lambda * fmin(fmax(uv, 1e-6), 1e32);
-            S[i][j] = uv - T[upidx(6, a, b)] - B[6 * i + j];
+            S[i][j] = uv - T[upidx(ND, a, b)] - B[ND * i + j];
             Li[i][j] = 0.0;
         }
-    double* So = d.Sfull + 36 * (size_t)d.bsr_diag[c];
-    double dg[6];
+    double* So = d.Sfull + NN * (size_t)d.bsr_diag[c];
+    double dg[ND];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < ND; ++i) {
         dg[i] = S[i][i];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { So[6 * i + j] = S[i][j]; A[i][j] = 0.5 * (S[i][j] + S[j][i]); }
+        for (int j = 0; j < ND; ++j) { So[ND * i + j] = S[i][j]; A[i][j] = 0.5 * (S[i][j] + S[j][i]); }
     }
-    const bool ok = spd6_inverse(A, Ai, Li);
+    const bool ok = spd_inverse(A, Ai, Li);
     if (!ok) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < ND; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < ND; ++j) {
                 Ai[i][j] = (i == j) ? 1.0 / fmax(fabs(dg[i]), 1e-300) : 0.0;
                 Li[i][j] = (i == j) ? 1.0 / sqrt(fmax(fabs(dg[i]), 1e-300)) : 0.0;
             }
     }
-    double* Mo = d.Minv + 36 * (size_t)c;
+    double* Mo = d.Minv + NN * (size_t)c;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < ND; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) Mo[6 * i + j] = Ai[i][j];
-    const double* g = U + 21;
-    double r[6];
+        for (int j = 0; j < ND; ++j) Mo[ND * i + j] = Ai[i][j];
+    const double* g = U + NU;
+    double r[ND];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        r[i] = -g[i] + T[21 + i];
-        d.rhs[6 * (size_t)c + i] = r[i];
+    for (int i = 0; i < ND; ++i) {
+        r[i] = -g[i] + T[NU + i];
+        d.rhs[ND * (size_t)c + i] = r[i];
     }
-    if (f.F == nullptr) return;
-    double* Fo = const_cast<double*>(f.F) + 36 * (size_t)c;
-    double* bo = const_cast<double*>(f.bhat) + 6 * (size_t)c;
-    double FS[6][6];                // F S
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double lij = j <= i ? Li[i][j] : 0.0;
-            Fo[6 * i + j] = lij;
-            v += lij * r[j];
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k <= i; ++k) t += Li[i][k] * S[k][j];
-            FS[i][j] = t;
-        }
-        bo[i] = v;
-    }
-    double* Ho = const_cast<double*>(f.Shat) + 36 * (size_t)d.bsr_diag[c];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
+    if constexpr (ND == 6) {        // the single-launch PCG is written for 6x6 blocks
+        if (f.F == nullptr) return;
+        double* Fo = const_cast<double*>(f.F) + 36 * (size_t)c;
+        double* bo = const_cast<double*>(f.bhat) + 6 * (size_t)c;
+        double FS[6][6];                // F S
+    #pragma unroll
+        for (int i = 0; i < 6; ++i) {
             double v = 0.0;
-#pragma unroll
-            for (int l = 0; l <= j; ++l) v += FS[i][l] * Li[j][l];
-            Ho[6 * i + j] = v;
+    #pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const double lij = j <= i ? Li[i][j] : 0.0;
+                Fo[6 * i + j] = lij;
+                v += lij * r[j];
+                double t = 0.0;
+    #pragma unroll
+                for (int k = 0; k <= i; ++k) t += Li[i][k] * S[k][j];
+                FS[i][j] = t;
+            }
+            bo[i] = v;
         }
+        double* Ho = const_cast<double*>(f.Shat) + 36 * (size_t)d.bsr_diag[c];
+    #pragma unroll
+        for (int i = 0; i < 6; ++i)
+    #pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double v = 0.0;
+    #pragma unroll
+                for (int l = 0; l <= j; ++l) v += FS[i][l] * Li[j][l];
+                Ho[6 * i + j] = v;
+            }
+    }
 }
 
 // k_finish_offdiag, one thread per element of every upper off-diagonal block: both orientations
 // of the block in the full matrix and, for the single-launch PCG, of the scaled block
 // F_r S_rc F_c' (its transpose is the scaled S_cr).
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_finish_offdiag(Dev d, FusedPcg f) {
+    constexpr int NN = ND * ND;
     const int t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= d.n_ublk * 36) return;
-    const int u = t / 36, e = t - 36 * u, i = e / 6, j = e - 6 * i;
+    if (t >= d.n_ublk * NN) return;
+    const int u = t / NN, e = t - NN * u, i = e / ND, j = e - ND * i;
     const int r = d.ublk_r[u], c = d.ublk_c[u];
     if (r == c) return;
-    const size_t pos = 36 * (size_t)d.ublk_pos[u] + e, pos_t = 36 * (size_t)d.ublk_pos_t[u] + 6 * j + i;
+    const size_t pos = NN * (size_t)d.ublk_pos[u] + e, pos_t = NN * (size_t)d.ublk_pos_t[u] + ND * j + i;
     const double v = -d.Bsum[t];
     d.Sfull[pos] = v;
     d.Sfull[pos_t] = v;
-    if (f.F == nullptr) return;
-    const double* Fi = f.F + 36 * (size_t)r + 6 * i;
-    const double* Fj = f.F + 36 * (size_t)c + 6 * j;
-    const double* B = d.Bsum + 36 * (size_t)u;
-    double s = 0.0;
+    if constexpr (ND == 6) {
+        if (f.F == nullptr) return;
+        const double* Fi = f.F + 36 * (size_t)r + 6 * i;
+        const double* Fj = f.F + 36 * (size_t)c + 6 * j;
+        const double* B = d.Bsum + 36 * (size_t)u;
+        double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        double tk = 0.0;
+        for (int k = 0; k < 6; ++k) {
+            double tk = 0.0;
 #pragma unroll
-        for (int l = 0; l < 6; ++l) tk += B[6 * k + l] * Fj[l];
-        s += Fi[k] * tk;
+            for (int l = 0; l < 6; ++l) tk += B[6 * k + l] * Fj[l];
+            s += Fi[k] * tk;
+        }
+        double* H = const_cast<double*>(f.Shat);
+        H[pos] = -s;
+        H[pos_t] = -s;
     }
-    double* H = const_cast<double*>(f.Shat);
-    H[pos] = -s;
-    H[pos_t] = -s;
 }
 
-// y = S x on the block-CSR matrix, one thread per (camera, row of the block); 42 cameras per
+// y = S x on the block-CSR matrix, one thread per (camera, row of the block); 42 (28) cameras per
 // workgroup.  Diagnostic entry (sfmba_schur_matvec); PCG uses k_pcg_spmv_bsr.
-constexpr int kCamsPerBlock = 42;
-
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_bsr_spmv(Dev d, const double* __restrict__ x, double* __restrict__ y) {
-    const int local = threadIdx.x / 6, k = threadIdx.x - 6 * local;
-    const int c = blockIdx.x * kCamsPerBlock + local;
-    if (local >= kCamsPerBlock || c >= d.n_cam) return;
+    constexpr int kCams = kBlock / ND, NN = ND * ND;
+    const int local = threadIdx.x / ND, k = threadIdx.x - ND * local;
+    const int c = blockIdx.x * kCams + local;
+    if (local >= kCams || c >= d.n_cam) return;
     double acc = 0.0;
     const int b0 = d.bsr_ptr[c], b1 = d.bsr_ptr[c + 1];
     for (int b = b0; b < b1; ++b) {
-        const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
-        const double2* xv = reinterpret_cast<const double2*>(x + 6 * (size_t)d.bsr_col[b]);
-        const double2 s0 = s[0], s1 = s[1], s2 = s[2];
-        const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
-        acc += s0.x * x0.x + s0.y * x0.y + s1.x * x1.x + s1.y * x1.y + s2.x * x2.x + s2.y * x2.y;
+        const double* s = d.Sfull + NN * (size_t)b + ND * k;
+        const double* xv = x + ND * (size_t)d.bsr_col[b];
+        if constexpr (ND % 2 == 0) {
+            const double2* s2 = reinterpret_cast<const double2*>(s);
+            const double2* x2 = reinterpret_cast<const double2*>(xv);
+#pragma unroll
+            for (int i = 0; i < ND / 2; ++i) { const double2 a = s2[i], v = x2[i]; acc += a.x * v.x + a.y * v.y; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) acc += s[i] * xv[i];
+        }
     }
-    y[6 * (size_t)c + k] = acc;
+    y[ND * (size_t)c + k] = acc;
 }
 
-// Dense lower-triangular copy of S (row-major n x n, n = 6 n_cam) for the Cholesky solver.
-__global__ __launch_bounds__(kBlock) void k_bsr_to_dense(Dev d, double* __restrict__ A, int n) {
+// Dense lower-triangular copy of S (row-major n x n, n = ND n_cam) for the Cholesky solver.
+__global__ __launch_bounds__(kBlock) void k_bsr_to_dense(Dev d, double* __restrict__ A, int n, int nd) {
+    const int nn = nd * nd;
     const int t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= d.nnzb * 36) return;
-    const int b = t / 36, e = t - 36 * b, i = e / 6, j = e - 6 * i;
+    if (t >= d.nnzb * nn) return;
+    const int b = t / nn, e = t - nn * b, i = e / nd, j = e - nd * i;
     // row camera of block b: binary search in bsr_ptr
     int lo = 0, hi = d.n_cam;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (d.bsr_ptr[mid] <= b) lo = mid; else hi = mid;
     }
-    const int row = 6 * lo + i, col = 6 * d.bsr_col[b] + j;
+    const int row = nd * lo + i, col = nd * d.bsr_col[b] + j;
     A[(size_t)row * n + col] = d.Sfull[t];
 }
 
-int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerBlock); }
+int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kBlock / cam_dim(d)); }
 
 
 void launch_schur_pairs(const Dev& d, hipStream_t st) {
-    if (d.n_pchunks > 0)
-        hipLaunchKernelGGL(k_schur_pairs, dim3(cdiv(d.n_pchunks, kBlock / 64)), dim3(kBlock), 0, st, d);
+    if (d.n_pchunks == 0) return;
+    const dim3 grid(cdiv(d.n_pchunks, kBlock / 64));
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_schur_pairs<Bal>), grid, dim3(kBlock), 0, st, d);
+    else hipLaunchKernelGGL((k_schur_pairs<Pinhole>), grid, dim3(kBlock), 0, st, d);
 }
 void launch_block_reduce(const Dev& d, hipStream_t st) {
+    const int nn = cam_dim(d) * cam_dim(d);
     if (d.n_ublk > 0)
-        hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d);
+        hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, nn);
 }
 void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st) {
     FusedPcg f{};
     if (scaled) f = *scaled;
-    hipLaunchKernelGGL(k_finish_diag, dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, tpart, f);
-    if (d.n_ublk > 0)
-        hipLaunchKernelGGL(k_finish_offdiag, dim3(cdiv(d.n_ublk * 36, kBlock)), dim3(kBlock), 0, st, d, f);
+    const int nn = cam_dim(d) * cam_dim(d);
+    if (d.model == MODEL_BAL) {
+        hipLaunchKernelGGL((k_finish_diag<Bal>), dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, tpart, f);
+        if (d.n_ublk > 0)
+            hipLaunchKernelGGL((k_finish_offdiag<Bal::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
+    } else {
+        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, tpart, f);
+        if (d.n_ublk > 0)
+            hipLaunchKernelGGL((k_finish_offdiag<Pinhole::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
+    }
 }
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st) {
-    hipLaunchKernelGGL(k_bsr_spmv, dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_bsr_spmv<Bal::ND>), dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y);
+    else hipLaunchKernelGGL((k_bsr_spmv<Pinhole::ND>), dim3(bsr_blocks(d)), dim3(kBlock), 0, st, d, x, y);
 }
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st) {
-    hipLaunchKernelGGL(k_bsr_to_dense, dim3(cdiv(d.nnzb * 36, kBlock)), dim3(kBlock), 0, st, d, A, n);
+    const int nd = cam_dim(d);
+    hipLaunchKernelGGL(k_bsr_to_dense, dim3(cdiv(d.nnzb * nd * nd, kBlock)), dim3(kBlock), 0, st, d, A, n, nd);
 }
 
 }  // namespace sfmba

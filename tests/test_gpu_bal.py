@@ -18,6 +18,12 @@ from structure_from_motion_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+# linear-solver paths of this model: matrix-free Schur product, explicit block-sparse reduced matrix
+# (9x9 blocks) with a launch per PCG iteration, dense Cholesky of the explicit matrix
+SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
+           "pcg-explicit": dict(linear_solver=1, schur_mode=2),
+           "dense": dict(linear_solver=2)}
+
 
 def make_engine(g, **opts):
     eng = E.Engine(camera_model="bal", **opts)
@@ -86,11 +92,12 @@ def _system(g, jc, jp, r, lam):
     return dict(U=U, gc=gc, V=V, gp=gp, S=S, rhs=rhs.reshape(nc, 9), dc=dc.reshape(nc, 9), dp=dp.reshape(npt, 3))
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("name", ["bal_tiny_5_60_200", "bal_shuffled_9_200_700"])
-def test_blocks_schur_product_and_step_match_dense_algebra(name):
+def test_blocks_schur_product_and_step_match_dense_algebra(name, solver):
     g = load_golden(name)
     lam = 1e-3
-    with make_engine(g, pcg_rtol=1e-14, pcg_max_iter=2000) as eng:
+    with make_engine(g, pcg_rtol=1e-14, pcg_max_iter=2000, **SOLVERS[solver]) as eng:
         jc, jp = eng.jacobian_blocks()
         r = eng.residuals().reshape(-1, 2)
         ref = _system(g, jc, jp, r, lam)
@@ -107,19 +114,22 @@ def test_blocks_schur_product_and_step_match_dense_algebra(name):
         x[:, 6:] *= [1e-2, 1e-3, 1e-3]          # tangent numbers of very different scale
         assert rel_err(eng.schur_matvec(x), (ref["S"] @ x.ravel()).reshape(nc, 9)) <= 1e-10
         dc, dp, iters = eng.solve_step()
-        assert iters >= 1
+        assert (iters == 0) if solver == "dense" else (iters >= 1)
         # the step in the metric of the problem: J step, which the ill-scaled columns do not distort
         pred = np.einsum("nki,ni->nk", jc, dc[g["camera_indices"]]) + np.einsum("nki,ni->nk", jp, dp[g["point_indices"]])
         want = np.einsum("nki,ni->nk", jc, ref["dc"][g["camera_indices"]]) + np.einsum("nki,ni->nk", jp, ref["dp"][g["point_indices"]])
         assert rel_err(pred, want) <= 1e-6
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("name", bal_golden_names())
-def test_solve_with_reference_tolerances_not_worse_than_scipy(name):
+def test_solve_with_reference_tolerances_not_worse_than_scipy(name, solver):
     g = load_golden(name)
-    cams, pts, res = bal.solve(g["camera_params"], g["points_3d"], g["camera_indices"], g["point_indices"], g["points_2d"])
+    cams, pts, res = bal.solve(g["camera_params"], g["points_3d"], g["camera_indices"], g["point_indices"], g["points_2d"],
+                               **SOLVERS[solver])
     assert res["success"] and res["status"] in (1, 2, 3, 4)
-    assert res["linear_solver"] == 1 and res["schur_mode"] == 1
+    assert res["linear_solver"] == (2 if solver == "dense" else 1)
+    assert res["schur_mode"] == (1 if solver == "pcg-implicit" else 2) and res["pcg_single_launch"] == 0
     assert abs(res["initial_cost"] - float(g["ref_initial_cost"])) <= 1e-10 * float(g["ref_initial_cost"])
     assert res["final_cost"] <= float(g["ref_cost"]) * (1 + 1e-6)
     # the returned 9-number cameras reproduce the reported cost under the oracle's fun()
@@ -128,10 +138,11 @@ def test_solve_with_reference_tolerances_not_worse_than_scipy(name):
     assert np.linalg.norm(cams[:, :3], axis=1).max() <= np.pi + 1e-12
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("name", bal_golden_names())
-def test_converged_cost_matches_scipy(name):
+def test_converged_cost_matches_scipy(name, solver):
     g = load_golden(name)
-    with make_engine(g, ftol=1e-15, xtol=1e-15, gtol=1e-12, max_iterations=100, pcg_rtol=1e-3) as eng:
+    with make_engine(g, ftol=1e-15, xtol=1e-15, gtol=1e-12, max_iterations=100, pcg_rtol=1e-3, **SOLVERS[solver]) as eng:
         st = eng.solve()
     assert abs(st.final_cost - float(g["tight_cost"])) <= 1e-6 * float(g["tight_cost"])
 
@@ -151,10 +162,11 @@ def test_parameters_round_trip_through_the_device_layout():
     assert np.linalg.norm(back[:, :3], axis=1).max() <= np.pi
 
 
+@pytest.mark.parametrize("solver", list(SOLVERS))
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_sharded_solve_matches_single_handle(nranks):
+def test_sharded_solve_matches_single_handle(nranks, solver):
     g = load_golden("bal_shuffled_9_200_700")
-    with make_engine(g) as eng:
+    with make_engine(g, **SOLVERS[solver]) as eng:
         ref = eng.solve()
         ref_cams, ref_pts = eng.get_params()
     group = E.local_group_create(nranks)
@@ -162,7 +174,7 @@ def test_sharded_solve_matches_single_handle(nranks):
 
     def work(r):
         try:
-            with E.Engine(camera_model="bal", rank=r, nranks=nranks) as eng:
+            with E.Engine(camera_model="bal", rank=r, nranks=nranks, **SOLVERS[solver]) as eng:
                 eng.set_problem(g["camera_params"], g["points_3d"], g["camera_indices"], g["point_indices"], g["points_2d"], None)
                 eng.comm_init_local(group)
                 st = eng.solve()
@@ -195,7 +207,8 @@ def test_solve_from_a_file():
     assert abs(b.cost(prob, cams, pts) - res["final_cost"]) <= 1e-9 * res["final_cost"]
 
 
-def test_irregular_structure():
+@pytest.mark.parametrize("solver", list(SOLVERS))
+def test_irregular_structure(solver):
     # tracks longer than a wavefront, a camera over several chunks, points seen once, a camera nobody sees
     rng = np.random.default_rng(8)
     p = syn.make_bal_problem(80, 600, 1200, seed=8, window=12)
@@ -215,7 +228,7 @@ def test_irregular_structure():
     g["n_obs"] = g["camera_indices"].size
     assert np.bincount(g["point_indices"]).max() > 64 and np.bincount(g["camera_indices"]).max() > 512
     lam = 1e-3
-    with make_engine(g, pcg_rtol=1e-14, pcg_max_iter=3000) as eng:
+    with make_engine(g, pcg_rtol=1e-14, pcg_max_iter=3000, **SOLVERS[solver]) as eng:
         x0, args = b.pack(g)
         assert elementwise_rel(eng.residuals(), b.fun(x0, *args)) <= 1e-10
         jc, jp = eng.jacobian_blocks()
@@ -236,8 +249,6 @@ def test_irregular_structure():
 
 def test_errors():
     g = load_golden("bal_tiny_5_60_200")
-    with pytest.raises(E.EngineError):
-        make_engine(g, linear_solver=2)                 # no dense factorisation for this model
     with E.Engine(camera_model="bal") as eng:
         with pytest.raises(ValueError):
             eng.set_problem(np.zeros((5, 12)), g["points_3d"], g["camera_indices"], g["point_indices"], g["points_2d"], None)
