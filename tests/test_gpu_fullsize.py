@@ -85,3 +85,41 @@ def test_full_solve_converges_and_is_reproducible(venice):
     assert abs(st.final_cost - expect) < 0.01 * expect
     assert st2.final_cost == st.final_cost
     assert pts.shape == (venice["n_points"], 3) and poses.shape == (venice["n_cameras"], 12)
+
+
+# ---- the 9-number camera of /root/reference/ba_test.py at the same size
+@pytest.fixture(scope="module")
+def venice_bal():
+    return syn.make_bal_problem(*syn.SHAPES["venice"], seed=0)
+
+
+def _bal_engine(p, **kw):
+    eng = Engine(camera_model="bal", **kw)
+    eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], None)
+    return eng
+
+
+def test_bal_residuals_at_truth_are_the_observation_noise(venice_bal):
+    with _bal_engine(venice_bal, max_iterations=1) as eng:
+        f0 = eng.residuals()
+        st = eng.solve()
+        assert abs(0.5 * float(f0 @ f0) - st.initial_cost) <= 1e-11 * st.initial_cost      # two kernels, one cost
+        eng.set_params(venice_bal["true_camera_params"], venice_bal["true_points_3d"])
+        f = eng.residuals()
+    rms = float(np.sqrt(np.mean(f * f)))
+    assert abs(rms - 0.5) < 0.002
+
+
+def test_bal_full_solve_converges_to_the_noise_floor_on_both_schur_paths(venice_bal):
+    costs = []
+    for mode in (2, 1):                                   # explicit 9x9 blocks, matrix-free
+        with _bal_engine(venice_bal, schur_mode=mode) as eng:
+            st = eng.solve()
+            cams, pts = eng.get_params()
+        assert st.status in (1, 2, 3, 4) and st.schur_mode == mode
+        n_res = 2 * venice_bal["n_obs"]; n_par = 9 * venice_bal["n_cameras"] + 3 * venice_bal["n_points"]
+        expect = 0.5 * (n_res - n_par) * 0.25
+        assert abs(st.final_cost - expect) < 0.01 * expect
+        assert cams.shape == (venice_bal["n_cameras"], 9) and pts.shape == (venice_bal["n_points"], 3)
+        costs.append(st.final_cost)
+    assert abs(costs[0] - costs[1]) <= 1e-6 * costs[0]
