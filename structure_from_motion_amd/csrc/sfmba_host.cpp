@@ -661,7 +661,9 @@ void phase_trial(H* h, double* dp_out) {
     reduce_scalars(h, SLOT_MODEL, SLOT_PCGFLAG - SLOT_MODEL + 1);
 }
 
-// Scalars of the linearisation: the slots, and the largest |g_p| over all partitions.
+// Scalars of the linearisation: the slots, and the largest |g_p| over all partitions.  They stay
+// in place until the next linearisation, so they can also be read together with the scalars of
+// the trial step that follows.
 double read_lin_scalars(H* h, double* sc) {
     std::vector<double> slots;
     if (h->has_comm()) {
@@ -716,6 +718,10 @@ void do_solve(H* h, sfmba_stats* out) {
     if (talk) { print_header(); print_row(0, st.nfev, cost, actual, step_norm, g_norm, true); }
     int accepted = 0;
     if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
+    // Unless every iteration is printed, the gradient norm of a new linearisation is not waited
+    // for: it is read with the scalars of the next trial step (one host synchronisation less per
+    // iteration), and a step computed from a point that turns out to satisfy gtol is dropped.
+    bool lin_pending = false;
     for (int it = 0; it < max_it && status < 0; ++it) {
         phase_damp(h, lambda);
         const bool pending = launch_linear_solve_async(h);
@@ -724,7 +730,13 @@ void do_solve(H* h, sfmba_stats* out) {
             HIP_TRY(hipMemsetAsync(h->scalars.p + SLOT_PCGFLAG, 0, sizeof(double), h->stream));
         }
         phase_trial(h, nullptr);
-        read_scalars(h, sc);
+        if (lin_pending) {
+            g_norm = read_lin_scalars(h, sc);
+            lin_pending = false;
+            if (g_norm < gtol) { status = SFMBA_STATUS_GTOL; break; }
+        } else {
+            read_scalars(h, sc);
+        }
         if (pending) {
             // identical on every rank: the flag is the ranks' sum, the state that of the same
             // replicated solve
@@ -767,12 +779,13 @@ void do_solve(H* h, sfmba_stats* out) {
             cost = cost_new;
             phase_linearize(h, lambda);  // also the gradient norm at the new iterate; damps for the next step
             st.njev++;
-            g_norm = read_lin_scalars(h, sc);
+            lin_pending = !talk;
+            if (!lin_pending) g_norm = read_lin_scalars(h, sc);
             if (talk) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, false);
             if (ft && xt) status = SFMBA_STATUS_FTOL_XTOL;
             else if (ft) status = SFMBA_STATUS_FTOL;
             else if (xt) status = SFMBA_STATUS_XTOL;
-            else if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
+            else if (!lin_pending && g_norm < gtol) status = SFMBA_STATUS_GTOL;
         } else {
             lambda *= nu;
             nu *= 2.0;
@@ -781,6 +794,10 @@ void do_solve(H* h, sfmba_stats* out) {
         if (status < 0 && st.nfev >= max_nfev) status = SFMBA_STATUS_MAX_NFEV;
     }
     if (status < 0) status = SFMBA_STATUS_MAX_NFEV;
+    if (lin_pending) {
+        g_norm = read_lin_scalars(h, sc);
+        if (status == SFMBA_STATUS_MAX_NFEV && g_norm < gtol) status = SFMBA_STATUS_GTOL;
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     auto t1 = std::chrono::steady_clock::now();
     if (h->profile) collect_spans(h);

@@ -355,3 +355,19 @@ def test_rccl_single_rank_communicator():
         poses, pts = eng.get_params()
     assert st.final_cost == a
     assert abs(o.cost(g, poses, pts) - a) <= 1e-9 * a
+
+
+@pytest.mark.parametrize("solver", list(SOLVERS))
+def test_gtol_termination_is_the_same_with_and_without_the_iteration_table(solver):
+    # without the table the gradient norm of a new linearisation is read one step late and a
+    # step taken from a point that already satisfies gtol is dropped: same result either way
+    g = load_golden("shuffled_9_200_700")
+    with make_engine(g, **SOLVERS[solver]) as eng:
+        opt = eng.solve().optimality
+    res = []
+    for verbose in (0, 2):
+        with make_engine(g, ftol=1e-15, xtol=1e-15, gtol=10.0 * opt, verbose=verbose, **SOLVERS[solver]) as eng:
+            st = eng.solve()
+            res.append((st.status, st.iterations, st.accepted, st.nfev, st.njev, st.final_cost, st.optimality))
+    assert res[0][0] == 1 and res[0][6] < 10.0 * opt
+    assert res[0] == res[1]
