@@ -179,7 +179,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0:
             with open(tpath) as f:
-                traffic = json.load(f).get("kernels", {}).get(kernel_name[dom], {}).get("hbm_bytes_per_launch")
+                recorded = json.load(f).get("kernels", {})
+            for name, rec in recorded.items():          # template arguments follow the name: k_schur_pairs<Pinhole>
+                if name.split("<")[0] == kernel_name[dom]:
+                    traffic = rec.get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "kernel": kernel_name[dom], "achieved": price(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": price(dom) / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": families[dom]["avg_us"],
