@@ -1,7 +1,9 @@
 // Device-side building blocks shared by every kernel of libsfmba: the projection model of
 // /root/reference/bundle_adjustment.py:10-31 (cv2.projectPoints with a fixed K and no
-// distortion), its analytic derivatives, tiny dense factorizations held in registers, and
-// wave/block reductions for 64-lane wavefronts.
+// distortion) and that of /root/reference/ba_test.py:62-89 (rotation vector, translation, focal
+// length, two radial coefficients) as two camera models with one interface, their analytic
+// derivatives, tiny dense factorizations held in registers, and wave/block reductions for
+// 64-lane wavefronts.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,8 +12,8 @@ namespace sfmba {
 
 struct Intr { double fx, fy, cx, cy; };
 
-// One camera as stored in HBM: 12 doubles = row-major rotation Q (9) then translation t (3),
-// 96 bytes, 16-byte aligned, so a gather is six 16-byte loads.
+// One pinhole camera as stored in HBM: 12 doubles = row-major rotation Q (9) then translation
+// t (3), 96 bytes, 16-byte aligned, so a gather is six 16-byte loads.
 struct Cam { double q[9]; double t[3]; };
 
 __device__ __forceinline__ Cam load_cam(const double2* __restrict__ cams, int c) {

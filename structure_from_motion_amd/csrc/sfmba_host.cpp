@@ -1557,7 +1557,7 @@ int sfmba_reprojection_errors(sfmba_handle* h, double* mean_error, int64_t* n_ob
         if (!mean_error) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_reprojection_errors: null output");
         refresh_dev(h);
         const size_t n = (size_t)h->n_cam * 2;
-        launch_reproj_cm(h->dev, h->tmp_b.p, h->stream);      // tmp_b holds >= 36 n_cam doubles
+        launch_reproj_cm(h->dev, h->tmp_b.p, h->stream);      // tmp_b holds >= 2 n_cam doubles
         allreduce(h, h->tmp_b.p, n);
         std::vector<double> v(n);
         HIP_TRY(hipMemcpyAsync(v.data(), h->tmp_b.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -46,7 +46,7 @@ struct PcgState {
 struct FusedPcg {
     int n_cam;
     const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;
-    const double* Shat;       // [nnzb][36]
+    const double* Shat;       // [nnzb][36] (6x6 blocks only)
     const double* F;          // [n_cam][36] lower triangular, row-major
     const double* bhat;       // [n_cam][6]
     double* vec;              // [4][n_cam][18] (r, w, s) records in rotating generation slots
@@ -124,10 +124,10 @@ struct Dev {
     const int* ublk_pos; const int* ublk_pos_t;   // [n_ublk] slots of (r,c) and (c,r) in Sfull
     const int* pchunk_blk; const int* pchunk_beg; // [n_pchunks], [n_pchunks+1]
     const int* pair_a; const int* pair_b; const int* pair_p;   // [n_pairs] camera-major indices of the two observations, point
-    double* pair_part;        // [n_pchunks][36]
-    double* Bsum;             // [n_ublk][36] sum W_a Vinv W_b' per upper block (all ranks' sum)
+    double* pair_part;        // [n_pchunks][ND * ND]
+    double* Bsum;             // [n_ublk][ND * ND] sum W_a Vinv W_b' per upper block (all ranks' sum)
     const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;   // [n_cam+1], [nnzb], [n_cam]
-    double* Sfull;            // [nnzb][36] row-major 6x6 blocks
+    double* Sfull;            // [nnzb][ND * ND] row-major blocks
     // scalars
     double* scal_part;  // [SLOT_COUNT][kMaxScalBlocks]
     double* scalars;    // [SLOT_COUNT]
@@ -142,10 +142,10 @@ inline int cam_words(int model) { return model == MODEL_BAL ? Bal::CW : Pinhole:
 void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);
 void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStream_t st);
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
-void launch_lin_cm(const Dev& d, hipStream_t st);               // chunk partials (27 values)
+void launch_lin_cm(const Dev& d, hipStream_t st);               // chunk partials (NU + ND values)
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);
-void launch_sdiag_cm(const Dev& d, hipStream_t st);             // chunk partials (27 values)
+void launch_sdiag_cm(const Dev& d, hipStream_t st);             // chunk partials (NU + ND values)
 void launch_precond(const Dev& d, double lambda, hipStream_t st);
 void launch_spmv_pm(const Dev& d, const double* x, const PcgState* state, hipStream_t st);
 void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hipStream_t st);   // chunk partials (6 values)

@@ -4,7 +4,8 @@
 // are contiguous, one thread owns one point and keeps its 3x3 block and 3-vector sums in
 // registers.  Camera-major ("cm"): the observations of one camera are contiguous and cut into
 // chunks of at most kChunk; one 64-lane wavefront owns one chunk, the camera is wave-uniform,
-// per-observation 6-vector / 6x6 contributions are summed in registers, reduced across the
+// per-observation camera-sized vector / block contributions (6 or 9 wide, by camera model) are
+// summed in registers, reduced across the
 // wavefront with cross-lane shuffles and written as one partial row per chunk; a per-camera
 // pass adds the chunk rows in a fixed order, so every sum is bitwise reproducible.
 //

@@ -1,12 +1,13 @@
 // Explicit block-sparse Schur complement of libsfmba (gfx950, fp64).
 //
-// S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p' has a 6x6 block for every pair of
+// S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p' has an ND x ND block (ND = 6 or 9
+// tangent numbers per camera, by camera model) for every pair of
 // cameras that share a point.  The host lists, per upper block (r <= c), the pairs of distinct
 // observations (a, b) of one point with camera(a) = r and camera(b) = c (an observation paired
 // with itself belongs to the diagonal block and is summed by the camera-major pass k_sdiag_cm), sorted by block and cut
 // into chunks; one wavefront owns one chunk, both cameras are wave-uniform, every lane forms
-//     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (6x2 . 2x2 . 2x6)
-// for its pairs from the stored camera-major seeds, sums in registers, and the wavefront reduces the 36 sums
+//     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (ND x 2 . 2x2 . 2 x ND)
+// for its pairs from the stored camera-major seeds, sums in registers, and the wavefront reduces the ND^2 sums
 // through an LDS tile into one partial row per chunk.  A per-block pass adds the chunk rows
 // in fixed order (bitwise reproducible, no atomics), a finishing pass mirrors the upper blocks
 // into a full block-CSR matrix and adds the damped U blocks on the diagonal.  The reduced system
