@@ -19,7 +19,7 @@ from scipy.sparse import lil_matrix
 
 from .engine import Engine, TERMINATION_MESSAGES
 
-__all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment"]
+__all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment", "solve_arrays", "solve_npz"]
 
 _fun_cache = {"key": None, "engine": None, "keep": None}
 
@@ -125,6 +125,7 @@ class BundleAdjustment:
         self.result = None
         self.reprojection_error = None      # per view, filled by optimize()
         self.reprojection_count = None
+        self._poses = self._points_3d = None
 
     def view2idx(self):
         """
@@ -186,7 +187,46 @@ class BundleAdjustment:
         self.result = stats.as_dict()
         self.result["message"] = TERMINATION_MESSAGES[stats.status]
         self.result["success"] = stats.status > 0
+        self._poses, self._points_3d = poses, points_3d
         return poses, points_3d
+
+    def write_back(self, print_error=True):
+        """
+        What the reference's driver does with the result of ``optimize()`` (main.py:116-123):
+        the refined points go to ``wpSet.world_points``; every view receives its rotation (3 x 3)
+        and translation (3 x 1), its ``world_points`` table (n x 5 rows ``[u, v, X, Y, Z]``, one per
+        correspondence that names the view, in correspondence order: ``ImageView.update_world_points``,
+        view.py:121-132) and, with ``print_error``, the line ``ImageView.reproject_view`` prints
+        (view.py:103-119).  The tables are cut out of the packed arrays without a loop over the
+        correspondences, and the per-view mean errors are the ones the GPU computed in ``optimize()``.
+        Returns the per-view mean reprojection errors.
+        """
+        if getattr(self, "_poses", None) is None:
+            raise RuntimeError("write_back: call optimize() first")
+        poses, points_3d = self._poses, self._points_3d
+        self.wpSet.world_points = points_3d
+        ci2 = np.asarray(self.camera_indices).reshape(-1, 2)
+        uv2 = np.asarray(self.points_2d, dtype=np.float64).reshape(-1, 2, 2)
+        for j, view in enumerate(self.completed_views):
+            view.rotation = poses[j, :9].reshape(3, 3)
+            view.translation = poses[j, 9:].reshape(3, 1)
+            k = self.view_idx[view.id]
+            first = ci2[:, 0] == k
+            second = (ci2[:, 1] == k) & ~first           # a row naming the view twice counts once, as its first entry
+            rows = np.flatnonzero(first | second)
+            uv = np.where(first[rows, None], uv2[rows, 0], uv2[rows, 1])
+            view.world_points = np.hstack((uv, points_3d[rows])) if rows.size else np.empty((0, 5))
+            if print_error:
+                print(f"Reprojection error for image{getattr(view, 'name', view.id)} is {self.reprojection_error[k]}")
+        return self.reprojection_error
+
+
+def solve_npz(path, K, **options):
+    """File-level entry point: solve an ``optimize_data.npz`` dump (the five arrays written at
+    bundle_adjustment.py:125-126) and return ``(poses, points_3d, stats dict)``."""
+    with np.load(path, allow_pickle=False) as z:
+        arrays = [z[k] for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d")]
+    return solve_arrays(*arrays, K, **options)
 
 
 def solve_arrays(camera_params, points_3d, camera_indices, point_indices, points_2d, K, **options):

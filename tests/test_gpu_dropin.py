@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 class FakeView:            # the attributes bundle_adjustment.py:98-105 reads from an ImageView
     def __init__(self, vid, R, t):
         self.id, self.rotation, self.translation = vid, R, t.reshape(3, 1)
+        self.name = vid
+        self.world_points = np.empty((0, 5))
 
 
 class FakeWorldPoints:     # WorldPoints.py:6-20: world_points + correspondences DataFrame
@@ -65,6 +67,46 @@ def test_optimize_matches_reference_contract(tmp_path, monkeypatch, capsys, capl
         sel = p["camera_indices"] == j
         assert b.reprojection_count[j] == sel.sum()
         assert abs(b.reprojection_error[j] - err[sel].mean()) <= 1e-10 * err[sel].mean()
+
+
+def test_write_back_does_what_the_driver_loop_does(tmp_path, monkeypatch, capsys):
+    # main.py:116-123: points to the world-point set, pose and the (u, v, X, Y, Z) table to every
+    # view, one "Reprojection error" line per view
+    monkeypatch.chdir(tmp_path)
+    p, views, wp = _scene()
+    b = ba.BundleAdjustment(wp, p["K"], np.zeros((1, 5)), views, verbose=0)
+    with pytest.raises(RuntimeError):
+        b.write_back()
+    poses, points_3d = b.optimize()
+    capsys.readouterr()
+    errs = b.write_back()
+    lines = capsys.readouterr().out.strip().split("\n")
+    assert wp.world_points is points_3d and len(lines) == 6
+    for j, view in enumerate(views):
+        assert np.array_equal(view.rotation, poses[j, :9].reshape(3, 3)) and view.translation.shape == (3, 1)
+        # the table ImageView.update_world_points builds with its loop over the correspondences (view.py:121-132)
+        want = np.empty((0, 5))
+        for i, row in wp.correspondences.iterrows():
+            ids = row["ViewId"]
+            if view.id in ids:
+                want = np.append(want, [np.hstack((row["FeatureIndex"][ids.index(view.id)], points_3d[i]))], axis=0)
+        assert np.array_equal(view.world_points, want)
+        # the mean of calculate_reprojection_error over that table (view.py:103-119, utils.py:337-352)
+        Y = view.world_points[:, 2:] @ view.rotation.T + view.translation.ravel()
+        uvp = (Y @ p["K"].T)
+        uvp = uvp[:, :2] / uvp[:, 2:3]
+        mean = np.linalg.norm(uvp - view.world_points[:, :2], axis=1).mean()
+        assert abs(errs[j] - mean) <= 1e-9 * mean
+        assert lines[j] == f"Reprojection error for image{view.name} is {errs[j]}"
+
+
+def test_solve_npz_reads_the_dump_optimize_writes(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    p, views, wp = _scene()
+    b = ba.BundleAdjustment(wp, p["K"], np.zeros((1, 5)), views, verbose=0)
+    poses, points_3d = b.optimize()
+    poses2, pts2, st = ba.solve_npz(tmp_path / "optimize_data.npz", p["K"])
+    assert st["success"] and np.array_equal(poses, poses2) and np.array_equal(points_3d, pts2)
 
 
 def test_unknown_view_id_raises_key_error(tmp_path, monkeypatch):
