@@ -582,8 +582,18 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
     const int slot = first_slot + blockIdx.x;
     const bool is_max = (max_mask >> blockIdx.x) & 1u;
     const double* part = d.scal_part + (size_t)slot * kMaxScalBlocks;
+    // eight loads in flight per thread (the order of the additions is fixed all the same)
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += 8 * 1024) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; x[u] = i < nblocks ? part[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = is_max ? fmax(a[u], x[u]) : a[u] + x[u];
+    }
     double v = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 1024) v = is_max ? fmax(v, part[i]) : v + part[i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v = is_max ? fmax(v, a[u]) : v + a[u];
     double r = is_max ? block_max(v, red) : block_sum(v, red);
     if (threadIdx.x == 0) d.scalars[slot] = r;
 }
