@@ -126,11 +126,11 @@ __global__ __launch_bounds__(kBlock) void k_pcg_spmv_bsr(Dev d, int cur) {
     const double* __restrict__ z = d.pz;
     const double* __restrict__ po = d.pp[cur];
     double acc = 0.0;
-    if (c < d.n_cam && sub < kSlots) {
-        const int b1 = d.bsr_ptr[c + 1];
-        for (int b = d.bsr_ptr[c] + sub; b < b1; b += kSlots) {
-            const size_t col = ND * (size_t)d.bsr_col[b];
-            if constexpr (ND == 6) {
+    if constexpr (ND == 6) {
+        if (c < d.n_cam && sub < kSlots) {
+            const int b1 = d.bsr_ptr[c + 1];
+            for (int b = d.bsr_ptr[c] + sub; b < b1; b += kSlots) {
+                const size_t col = 6 * (size_t)d.bsr_col[b];
                 const double2* s = reinterpret_cast<const double2*>(d.Sfull + 36 * (size_t)b + 6 * k);
                 const double2* zv = reinterpret_cast<const double2*>(z + col);
                 const double2* pv = reinterpret_cast<const double2*>(po + col);
@@ -140,10 +140,43 @@ __global__ __launch_bounds__(kBlock) void k_pcg_spmv_bsr(Dev d, int cur) {
                 acc += s0.x * (z0.x + h.beta * p0.x) + s0.y * (z0.y + h.beta * p0.y) +
                        s1.x * (z1.x + h.beta * p1.x) + s1.y * (z1.y + h.beta * p1.y) +
                        s2.x * (z2.x + h.beta * p2.x) + s2.y * (z2.y + h.beta * p2.y);
-            } else {
-                const double* s = d.Sfull + NN * (size_t)b + ND * k;
+            }
+        }
+    } else {
+        // rows of an odd width cannot be read with aligned 16-byte loads, and one 8-byte load per
+        // lane and column would touch every cache line of the group nine times: the kSlots blocks
+        // a wavefront works on are contiguous, so it copies them to LDS with coalesced loads and
+        // every lane reads its row from there
+        constexpr int kGroups = 1;              // slot groups staged at once (2 and 4 measured: no faster, 4 slower)
+        constexpr int kStage = kGroups * kSlots * NN, kLoads = (kStage + 63) / 64;
+        __shared__ double stage[kBlock / 64][kStage];
+        double* st = stage[w];
+        if (c < d.n_cam) {                      // c is the same for the whole wavefront
+            const int b1 = d.bsr_ptr[c + 1];
+            for (int gb = d.bsr_ptr[c]; gb < b1; gb += kGroups * kSlots) {
+                const int nblk = min(kGroups * kSlots, b1 - gb), n = nblk * NN;
+                const double* __restrict__ src = d.Sfull + NN * (size_t)gb;
+                double v[kLoads];
 #pragma unroll
-                for (int i = 0; i < ND; ++i) acc += s[i] * (z[col + i] + h.beta * po[col + i]);
+                for (int j = 0; j < kLoads; ++j) { const int i = lane + 64 * j; v[j] = i < n ? src[i] : 0.0; }
+#pragma unroll
+                for (int j = 0; j < kLoads; ++j) { const int i = lane + 64 * j; if (i < kStage) st[i] = v[j]; }
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+                if (sub < kSlots) {
+#pragma unroll
+                    for (int g = 0; g < kGroups; ++g) {
+                        const int bl = g * kSlots + sub;
+                        if (bl < nblk) {
+                            const size_t col = ND * (size_t)d.bsr_col[gb + bl];
+                            const double* row = st + bl * NN + ND * k;
+#pragma unroll
+                            for (int i = 0; i < ND; ++i) acc += row[i] * (z[col + i] + h.beta * po[col + i]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
