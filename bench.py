@@ -25,12 +25,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, GB/s
 
 
-def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks):
+def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks, cam_dim=6):
     """Compulsory HBM bytes per launch of the per-launch kernels (int32 indices, f64 data).
 
     pairs    explicit Schur assembly k_schur_pairs: three indices per pair (12), every
              observation's three seed words once (24), every point's inverse block once (48), one
-             36-double partial row per chunk (288)
+             36-double partial row per chunk (288; 81 doubles for the 9-number camera)
     bsr      k_pcg_spmv_bsr: the block-CSR matrix once (288 + 4 per block, n_pairs here = blocks),
              three vectors read and two written per camera (240); k_pcg_fused: see main()
     spmv_pm  implicit matvec, point-major half: camera index + seed record per observation (36),
@@ -39,19 +39,26 @@ def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks):
     spmv_cm  implicit matvec, camera-major half: point index + seeds per observation (28),
              product gathered once per point (32), camera (96), 48 + 12 per chunk"""
     return {
-        "pairs": 12 * n_pairs + 24 * n_obs + 48 * n_pts + 288 * n_pair_chunks,
+        "pairs": 12 * n_pairs + 24 * n_obs + 48 * n_pts + 8 * cam_dim * cam_dim * n_pair_chunks,
         "spmv_pm": 40 * n_obs + 80 * n_pts + 120 * n_cam,
         "spmv_cm": 28 * n_obs + 32 * n_pts + 96 * n_cam + 60 * n_chunks,
     }
 
 
-def cpu_baseline(scale, seed):
+def cpu_baseline(scale, seed, camera_model="pinhole"):
     """scipy.optimize.least_squares with the reference's kwargs over the NumPy restatement of
     fun() on a scaled-down instance of the same synthetic workload."""
-    from oracle import ba_oracle as o
     from structure_from_motion_amd import synthetic as syn
-    p = syn.make_shape("venice", seed=seed, scale=scale)
-    r = o.solve_reference(p, use_lil=False)
+    if camera_model == "bal":
+        from oracle import bal_oracle as b
+        nc, npts, no = syn.SHAPES["venice"]
+        nc, npts = max(4, round(nc * scale)), max(8, round(npts * scale))
+        p = syn.make_bal_problem(nc, npts, min(max(round(no * scale), 2 * npts), 12 * npts), seed=seed)
+        r = b.solve_reference(p)
+    else:
+        from oracle import ba_oracle as o
+        p = syn.make_shape("venice", seed=seed, scale=scale)
+        r = o.solve_reference(p, use_lil=False)
     iters = max(r["nfev"] - 1, 1)
     return {
         "value": p["n_obs"] * iters / r["seconds"], "unit": "obs*iter/s", "cores": 1, "kind": "port",
@@ -77,6 +84,9 @@ def main():
     ap.add_argument("--linear-solver", type=int, default=0, help="0 auto, 1 PCG, 2 dense Cholesky")
     ap.add_argument("--schur-mode", type=int, default=0, help="0 auto, 1 implicit, 2 explicit")
     ap.add_argument("--pcg-mode", type=int, default=0, help="0 auto, 1 two launches per iteration, 2 single launch")
+    ap.add_argument("--camera-model", default="pinhole", choices=("pinhole", "bal"),
+                    help="pinhole: the 12-number camera of bundle_adjustment.py (the headline workload); "
+                         "bal: the 9-number camera of ba_test.py on the same scene")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +107,18 @@ def main():
         dist = None
         torch.cuda.set_device(local_rank)
 
-    p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
-    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode)
+    bal = args.camera_model == "bal"
+    if bal:
+        nc, npts, no = syn.SHAPES[args.shape]
+        if args.scale != 1.0:
+            nc, npts = max(4, round(nc * args.scale)), max(8, round(npts * args.scale))
+            no = min(max(round(no * args.scale), 2 * npts), min(12, nc) * npts)
+        p = syn.make_bal_problem(nc, npts, no, seed=args.seed)
+        p["K"] = None
+    else:
+        p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
+    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode,
+                       camera_model=args.camera_model)
     eng = Engine(device=local_rank, rank=rank, nranks=world, **solver_opts)
     t0 = time.time()
     eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
@@ -148,13 +168,15 @@ def main():
         chunk = int(os.environ.get("SFMBA_CHUNK", "512"))
         cam_counts = np.bincount(p["camera_indices"], minlength=p["n_cameras"])
         n_chunks = int(np.sum((cam_counts + chunk - 1) // chunk))
-        ab = algorithmic_bytes(n_obs, p["n_points"], p["n_cameras"], n_chunks, ps.schur_pairs, ps.schur_chunks)
+        ab = algorithmic_bytes(n_obs, p["n_points"], p["n_cameras"], n_chunks, ps.schur_pairs, ps.schur_chunks,
+                               cam_dim=9 if bal else 6)
         if ps.pcg_single_launch:
             # single-launch PCG: the matrix lives in registers; one iteration moves the 18-word
             # record of every gathered column and of every row written (through memory, past L2)
             ab["bsr"] = 144 * ps.schur_blocks + 144 * p["n_cameras"]
         else:
-            ab["bsr"] = 292 * ps.schur_blocks + 240 * p["n_cameras"]
+            cd = 9 if bal else 6
+            ab["bsr"] = (8 * cd * cd + 4) * ps.schur_blocks + 40 * cd * p["n_cameras"]
         families = {}
         for fam in ("linearize", "damp", "schur", "pairs", "bsr", "spmv_pm", "spmv_cm", "pcg_vec", "back", "cost", "dense"):
             n = getattr(ps, "n_" + fam)
@@ -177,7 +199,7 @@ def main():
         # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0:
+        if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0 and not bal:
             with open(tpath) as f:
                 recorded = json.load(f).get("kernels", {})
             for name, rec in recorded.items():          # template arguments follow the name: k_schur_pairs<Pinhole>
@@ -196,7 +218,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_scale, args.seed)
+        cpu = cpu_baseline(args.cpu_scale, args.seed, args.camera_model)
 
     if rank == 0:
         out = {
@@ -205,7 +227,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{args.shape}-shape synthetic problem, pinhole camera of bundle_adjustment.py (seed {args.seed}"
+            "config": {"workload": (f"{args.shape}-shape synthetic problem, "
+                                    + ("9-number camera of ba_test.py" if bal else "pinhole camera of bundle_adjustment.py")
+                                    + f" (seed {args.seed}"
                                     + (f", scale {args.scale}" if args.scale != 1.0 else "") + "): "
                                     f"{p['n_cameras']} cameras / {p['n_points']} points / {n_obs} observations; "
                                     "one step = one full LM solve (Schur complement + block-Jacobi PCG), "
