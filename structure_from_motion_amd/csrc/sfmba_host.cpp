@@ -979,14 +979,28 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     if (mode == 1) return;
     // pairs of this partition
     int64_t n_pairs = 0;
-    for (int p = 0; p < np; ++p) {            // (an observation with itself is not a pair: the diagonal
-        const int64_t k = pt_ptr[p + 1] - pt_ptr[p];      // blocks come from a camera-major pass)
-        n_pairs += k * (k - 1) / 2;
+    {
+        int ntc = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("SFMBA_THREADS")) ntc = std::max(1, atoi(e));
+        if (no < 200000) ntc = 1;
+        std::vector<int64_t> part((size_t)ntc, 0);
+        auto count = [&](int t) {
+            int64_t n = 0;
+            for (int p = (int)((int64_t)np * t / ntc); p < (int)((int64_t)np * (t + 1) / ntc); ++p) {
+                const int64_t k = pt_ptr[p + 1] - pt_ptr[p];      // (an observation with itself is not a pair: the
+                n += k * (k - 1) / 2;                               // diagonal blocks come from a camera-major pass)
+                for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a)     // same-camera duplicates inside a point add one entry each
+                    for (int b = a + 1; b < pt_ptr[p + 1]; ++b)
+                        if (pm_cam[a] == pm_cam[b]) ++n;
+            }
+            part[t] = n;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < ntc; ++t) th.emplace_back(count, t);
+        count(0);
+        for (auto& x : th) x.join();
+        for (int64_t n : part) n_pairs += n;
     }
-    for (int p = 0; p < np; ++p)              // same-camera duplicates inside a point add one entry each
-        for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a)
-            for (int b = a + 1; b < pt_ptr[p + 1]; ++b)
-                if (pm_cam[a] == pm_cam[b]) ++n_pairs;
     if (mode == 0 && (n_pairs > 24 * (int64_t)std::max(no, 1) || n_pairs > 1500000000LL)) return;
     if (n_pairs > 2000000000LL) fail(SFMBA_ERR_INVALID_ARGUMENT, "explicit Schur complement: too many observation pairs");
 
@@ -1208,11 +1222,31 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     HIP_TRY(hipSetDevice(h->device));
     h->has_problem = false;
     SetupTrace tr;
-    for (int64_t i = 0; i < n_obs; ++i) {
-        if (cam_idx[i] < 0 || cam_idx[i] >= n_cam)
-            fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)cam_idx[i], (long long)n_cam);
-        if (pt_idx[i] < 0 || pt_idx[i] >= n_pts)
+    // The sorts below run on several host threads.  Every pass gives thread t a range of the KEYS
+    // (points or cameras); each thread scans all observations in order and handles those whose key
+    // is its own, so the result is the stable sort a single thread produces, whatever the count.
+    int nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("SFMBA_THREADS")) nt = std::max(1, atoi(e));
+    if (n_obs < 200000) nt = 1;
+    auto run_threads = [&](auto&& body) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+        body(0);
+        for (auto& x : th) x.join();
+    };
+    auto share = [&](int64_t n, int t) { return n * t / nt; };     // thread t owns keys [share(n, t), share(n, t + 1))
+    {   // the first observation with an index out of range (threads split the observations here)
+        std::vector<int64_t> bad((size_t)nt, n_obs);
+        run_threads([&](int t) {
+            for (int64_t i = share(n_obs, t); i < share(n_obs, t + 1); ++i)
+                if (cam_idx[i] < 0 || cam_idx[i] >= n_cam || pt_idx[i] < 0 || pt_idx[i] >= n_pts) { bad[t] = i; break; }
+        });
+        const int64_t i = *std::min_element(bad.begin(), bad.end());
+        if (i < n_obs) {
+            if (cam_idx[i] < 0 || cam_idx[i] >= n_cam)
+                fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)cam_idx[i], (long long)n_cam);
             fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)pt_idx[i], (long long)n_pts);
+        }
     }
     h->n_cam = n_cam; h->n_pts_all = n_pts; h->n_obs_all = n_obs;
     h->model = model == SFMBA_CAMERA_BAL ? MODEL_BAL : MODEL_PINHOLE;
@@ -1222,7 +1256,10 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
 
     // observations per point, then the owned point range: contiguous, equal observation share
     std::vector<int> cnt((size_t)n_pts + 1, 0);
-    for (int64_t i = 0; i < n_obs; ++i) cnt[pt_idx[i] + 1]++;
+    run_threads([&](int t) {
+        const int64_t lo = share(n_pts, t), hi = share(n_pts, t + 1);
+        for (int64_t i = 0; i < n_obs; ++i) { const int64_t p = pt_idx[i]; if (p >= lo && p < hi) cnt[p + 1]++; }
+    });
     std::vector<int64_t> pre((size_t)n_pts + 1, 0);
     for (int64_t p = 0; p < n_pts; ++p) pre[p + 1] = pre[p] + cnt[p + 1];
     const int nr = std::max(1, h->opt.nranks), rk = nr > 1 ? h->opt.rank : 0;
@@ -1242,12 +1279,15 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     // caller's point id).  Points seen by the same cameras then sit next to each other in HBM:
     // the per-camera gathers of point data and the per-point gathers of camera data stay in L2.
     std::vector<int> min_cam((size_t)np, (int)n_cam);   // n_cam = "unobserved", sorted last
-    for (int64_t i = 0; i < n_obs; ++i) {
-        int64_t p = pt_idx[i];
-        if (p < h->pt_lo || p >= h->pt_hi) continue;
-        int& m = min_cam[p - h->pt_lo];
-        if ((int)cam_idx[i] < m) m = (int)cam_idx[i];
-    }
+    run_threads([&](int t) {
+        const int64_t lo = h->pt_lo + share(np, t), hi = h->pt_lo + share(np, t + 1);
+        for (int64_t i = 0; i < n_obs; ++i) {
+            const int64_t p = pt_idx[i];
+            if (p < lo || p >= hi) continue;
+            int& m = min_cam[p - h->pt_lo];
+            if ((int)cam_idx[i] < m) m = (int)cam_idx[i];
+        }
+    });
     std::vector<int> key_ptr((size_t)n_cam + 2, 0);
     for (int p = 0; p < np; ++p) key_ptr[min_cam[p] + 1]++;
     for (int64_t c = 0; c <= n_cam; ++c) key_ptr[c + 1] += key_ptr[c];
@@ -1265,30 +1305,41 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
     std::vector<int> pm_cam(no), pm_pt(no), pm_orig(no);
     std::vector<double2> pm_uv(no);
-    for (int64_t i = 0; i < n_obs; ++i) {
-        int64_t p = pt_idx[i];
-        if (p < h->pt_lo || p >= h->pt_hi) continue;
-        int q = old2new[p - h->pt_lo];
-        int j = fill[q]++;
-        pm_cam[j] = (int)cam_idx[i];
-        pm_pt[j] = q;
-        pm_orig[j] = (int)i;
-        pm_uv[j] = make_double2(points_2d[2 * i], points_2d[2 * i + 1]);
-    }
+    run_threads([&](int t) {
+        const int64_t lo = h->pt_lo + share(np, t), hi = h->pt_lo + share(np, t + 1);
+        for (int64_t i = 0; i < n_obs; ++i) {
+            const int64_t p = pt_idx[i];
+            if (p < lo || p >= hi) continue;
+            const int q = old2new[p - h->pt_lo];
+            const int j = fill[q]++;
+            pm_cam[j] = (int)cam_idx[i];
+            pm_pt[j] = q;
+            pm_orig[j] = (int)i;
+            pm_uv[j] = make_double2(points_2d[2 * i], points_2d[2 * i + 1]);
+        }
+    });
     tr.lap("validate + point-major sort");
     // camera-major order (stable counting sort of the point-major list by camera)
     std::vector<int> cam_ptr((size_t)n_cam + 1, 0);
-    for (int j = 0; j < no; ++j) cam_ptr[pm_cam[j] + 1]++;
+    run_threads([&](int t) {
+        const int lo = (int)share(n_cam, t), hi = (int)share(n_cam, t + 1);
+        for (int j = 0; j < no; ++j) { const int c = pm_cam[j]; if (c >= lo && c < hi) cam_ptr[c + 1]++; }
+    });
     for (int64_t c = 0; c < n_cam; ++c) cam_ptr[c + 1] += cam_ptr[c];
     std::vector<int> cfill(cam_ptr.begin(), cam_ptr.end() - 1);
     std::vector<int> cm_pt(no), pm2cm(no);
     std::vector<double2> cm_uv(no);
-    for (int j = 0; j < no; ++j) {
-        int k = cfill[pm_cam[j]]++;
-        pm2cm[j] = k;
-        cm_pt[k] = pm_pt[j];
-        cm_uv[k] = pm_uv[j];
-    }
+    run_threads([&](int t) {
+        const int lo = (int)share(n_cam, t), hi = (int)share(n_cam, t + 1);
+        for (int j = 0; j < no; ++j) {
+            const int c = pm_cam[j];
+            if (c < lo || c >= hi) continue;
+            const int k = cfill[c]++;
+            pm2cm[j] = k;
+            cm_pt[k] = pm_pt[j];
+            cm_uv[k] = pm_uv[j];
+        }
+    });
     // chunks: pieces of at most `chunk` observations of one camera
     if (const char* e = getenv("SFMBA_CHUNK")) { int v = atoi(e); if (v >= 64) h->chunk = v; }
     std::vector<int> chunk_cam, chunk_beg, cam_chunk_ptr((size_t)n_cam + 1, 0);
