@@ -407,12 +407,13 @@ void reduce_scalars(H* h, int first, int count) {
 // in scalars[SLOT_GMAX_CAM].  (Running the two halves on two streams was measured: no gain.)
 // `lambda` is the damping of the step that will follow (0 = not known): the points are then damped
 // in the same pass and phase_damp(lambda) finds that done.
-void phase_linearize(H* h, double lambda = 0.0) {
+// `grad_only`: the solve ends at this point and only its gradient norm is still wanted.
+void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false) {
     Scope t(h, F_LIN);
     refresh_dev(h);
-    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream);
-    h->damped_lambda = lambda > 0.0 ? lambda : -1.0;
-    launch_lin_cm(h->dev, h->stream);
+    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only);
+    h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
+    launch_lin_cm(h->dev, h->stream, grad_only);
     launch_chunk_reduce(h->dev, h->cv, h->UG.p, h->stream);
     if (h->has_comm()) {
         // one collective for the camera blocks and the gradient maximum over the points: the
@@ -777,7 +778,8 @@ void do_solve(H* h, sfmba_stats* out) {
             lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-15);
             nu = 2.0;
             cost = cost_new;
-            phase_linearize(h, lambda);  // also the gradient norm at the new iterate; damps for the next step
+            // also the gradient norm at the new iterate; damps for the next step, unless this was the last
+            phase_linearize(h, lambda, ft || xt);
             st.njev++;
             lin_pending = !talk;
             if (!lin_pending) g_norm = read_lin_scalars(h, sc);

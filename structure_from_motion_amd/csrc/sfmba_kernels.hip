@@ -124,7 +124,9 @@ __device__ __forceinline__ void damp_point(const Dev& d, int p, const double* Vi
 // (every other consumer rebuilds them from X and the camera it gathers anyway).
 // With lambda > 0 the writer lane also damps its point: Vinv = (V + lambda clamp(diag V))^-1 and
 // s0 = Vinv g_p, what k_damp_pm would otherwise read V and g_p back for.
-template <class M, bool kStore>
+// kGrad: only g_p's largest entry and the cost are wanted (the gradient norm at the point a solve
+// ends on): V_p is neither summed nor stored, nothing is damped.
+template <class M, bool kStore, bool kGrad = false>
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
     __shared__ double red[block_reduce_scratch<2>()];
     const int lane = threadIdx.x & 63;
@@ -148,18 +150,33 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
         }
         double a[3], b[3];
         M::jac_pt(ob, k.q, a, b);
-        acc[0] += a[0] * a[0] + b[0] * b[0];
-        acc[1] += a[0] * a[1] + b[0] * b[1];
-        acc[2] += a[0] * a[2] + b[0] * b[2];
-        acc[3] += a[1] * a[1] + b[1] * b[1];
-        acc[4] += a[1] * a[2] + b[1] * b[2];
-        acc[5] += a[2] * a[2] + b[2] * b[2];
+        if (!kGrad) {
+            acc[0] += a[0] * a[0] + b[0] * b[0];
+            acc[1] += a[0] * a[1] + b[0] * b[1];
+            acc[2] += a[0] * a[2] + b[0] * b[2];
+            acc[3] += a[1] * a[1] + b[1] * b[1];
+            acc[4] += a[1] * a[2] + b[1] * b[2];
+            acc[5] += a[2] * a[2] + b[2] * b[2];
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[6 + i] += a[i] * ru + b[i] * rv;
         cost += ru * ru + rv * rv;
     }
     bool writer;
-    if (t.is_long) {
+    if (kGrad) {
+        double g3[3] = {acc[6], acc[7], acc[8]};
+        if (t.is_long) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g3[i] = wave_sum(g3[i]);
+            writer = lane == 0;
+        } else {
+            seg_scan(g3, key, lane);
+            const int last = seg_last(key, lane);
+            writer = key >= 0 && last == lane;
+        }
+        if (writer) gmax = fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2])));
+        writer = false;
+    } else if (t.is_long) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) acc[i] = wave_sum(acc[i]);
         writer = lane == 0;
@@ -199,7 +216,9 @@ __device__ __forceinline__ void chunk_store(const Dev& d, int q, const double (&
 
 // Linearisation, camera-major half: seeds per observation (camera-major copy) and the chunk
 // partials of U_c (packed upper) and g_c.
-template <class M>
+// kGrad: only g_c is wanted (see k_lin_pm): the U part of the chunk row is written as zeros and the
+// camera-major seeds are left alone.
+template <class M, bool kGrad = false>
 __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
     constexpr int ND = M::ND, NU = M::NU, NV = M::NV;
     __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
@@ -220,18 +239,32 @@ __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
         double2 uv = d.cm_uv[k];
         double ru, rv;
         M::residual(ob, uv.x, uv.y, ru, rv);
-        d.cm_sx[k] = s.x; d.cm_sy[k] = s.y; d.cm_siz[k] = s.iz;
+        if (!kGrad) { d.cm_sx[k] = s.x; d.cm_sy[k] = s.y; d.cm_siz[k] = s.iz; }
         double jc[2 * ND];
         M::jac_cam(ob, jc);
-        int n = 0;
+        if (!kGrad) {
+            int n = 0;
 #pragma unroll
-        for (int i = 0; i < ND; ++i)
+            for (int i = 0; i < ND; ++i)
 #pragma unroll
-            for (int j = i; j < ND; ++j) acc[n++] += jc[i] * jc[j] + jc[ND + i] * jc[ND + j];
+                for (int j = i; j < ND; ++j) acc[n++] += jc[i] * jc[j] + jc[ND + i] * jc[ND + j];
+        }
 #pragma unroll
         for (int i = 0; i < ND; ++i) acc[NU + i] += jc[i] * ru + jc[ND + i] * rv;
     }
-    chunk_store<NV>(d, q, acc, lds, lane);
+    if (kGrad) {
+        double g[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) g[i] = wave_sum(acc[NU + i]);
+        double* o = d.chunk_part + NV * (size_t)q;
+        for (int i = lane; i < NU; i += 64) o[i] = 0.0;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) o[NU + i] = g[i];
+        }
+    } else {
+        chunk_store<NV>(d, q, acc, lds, lane);
+    }
 }
 
 // out[c][v] = sum over the chunks of camera c of chunk_part[q][v], fixed order.
@@ -670,9 +703,12 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     if (d.n_obs == 0) return;
     SFMBA_LAUNCH(d, k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), st, d, jc, jp);
 }
-void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st) {
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only) {
     const int nb = blocks_wtile(d);
-    if (nb > 0) {
+    if (nb > 0 && grad_only) {
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0);
+        else hipLaunchKernelGGL((k_lin_pm<Pinhole, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0);
+    } else if (nb > 0) {
         if (d.model == MODEL_BAL && store_seeds) hipLaunchKernelGGL((k_lin_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
         else if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
         else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
@@ -680,9 +716,16 @@ void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st
     }
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
 }
-void launch_lin_cm(const Dev& d, hipStream_t st) {
+void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only) {
     if (d.n_chunks == 0) return;
-    SFMBA_LAUNCH(d, k_lin_cm, dim3(blocks_chunk(d)), st, d);
+    const dim3 grid(blocks_chunk(d));
+    if (grad_only) {
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_cm<Bal, true>), grid, dim3(kBlock), 0, st, d);
+        else hipLaunchKernelGGL((k_lin_cm<Pinhole, true>), grid, dim3(kBlock), 0, st, d);
+    } else {
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_cm<Bal, false>), grid, dim3(kBlock), 0, st, d);
+        else hipLaunchKernelGGL((k_lin_cm<Pinhole, false>), grid, dim3(kBlock), 0, st, d);
+    }
 }
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_chunk_reduce, dim3(cdiv(d.n_cam * nvals, kBlock)), dim3(kBlock), 0, st, d, nvals, out);
