@@ -205,6 +205,7 @@ struct sfmba_handle {
     bool linearized = false;
     double lin_lambda = 0.0;
     double damped_lambda = -1.0;   // damping for which Vinv and s0 are current
+    bool have_v = false;           // V_p and g_p of the current linearisation are in memory
 
     // global shape and this partition
     int64_t n_cam = 0, n_pts_all = 0, n_obs_all = 0;
@@ -411,8 +412,9 @@ void reduce_scalars(H* h, int first, int count) {
 void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false) {
     Scope t(h, F_LIN);
     refresh_dev(h);
-    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only);
+    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only, /*keep_v=*/false);
     h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
+    h->have_v = !grad_only && !(lambda > 0.0);
     launch_lin_cm(h->dev, h->stream, grad_only);
     launch_chunk_reduce(h->dev, h->cv, h->UG.p, h->stream);
     if (h->has_comm()) {
@@ -429,6 +431,14 @@ void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false) {
     h->linearized = false;
 }
 
+// Vinv and V*^-1 g_p for another damping of the same linearisation: from V_p and g_p when they were
+// stored, otherwise by the point-major linearisation pass again (this time keeping them).
+void damp_points(H* h, double lambda) {
+    if (h->have_v) { launch_damp_pm(h->dev, lambda, h->stream); return; }
+    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, false, /*keep_v=*/true);
+    h->have_v = true;
+}
+
 // Damp with lambda: Vinv, V*^-1 g_p, block-Jacobi blocks, reduced right-hand side; in explicit
 // mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
@@ -438,7 +448,7 @@ void phase_damp(H* h, double lambda) {
         double* tpart = h->Bsum.p + (size_t)h->n_ublk * h->cd * h->cd;
         if (h->damped_lambda != lambda) {
             Scope t(h, F_DAMP);
-            launch_damp_pm(h->dev, lambda, h->stream);
+            damp_points(h, lambda);
         }
         {
             Scope t(h, F_DAMP);
@@ -461,7 +471,7 @@ void phase_damp(H* h, double lambda) {
         }
     } else {
         Scope t(h, F_DAMP);
-        if (h->damped_lambda != lambda) launch_damp_pm(h->dev, lambda, h->stream);
+        if (h->damped_lambda != lambda) damp_points(h, lambda);
         launch_sdiag_cm(h->dev, h->stream);
         launch_chunk_reduce(h->dev, h->cv, h->T.p, h->stream);
         allreduce(h, h->T.p, (size_t)h->n_cam * h->cv);

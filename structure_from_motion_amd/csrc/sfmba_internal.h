@@ -142,7 +142,8 @@ inline int cam_words(int model) { return model == MODEL_BAL ? Bal::CW : Pinhole:
 void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);
 void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStream_t st);
 // grad_only: cost and gradient maxima alone (the point a solve ends on); V, U, seeds are not produced
-void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only = false);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
+// keep_v: also store V_p and g_p when the points are damped in the same pass (lambda > 0)
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only = false, bool keep_v = true);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
 void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only = false);               // chunk partials (NU + ND values)
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);

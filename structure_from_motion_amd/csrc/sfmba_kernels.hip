@@ -127,7 +127,7 @@ __device__ __forceinline__ void damp_point(const Dev& d, int p, const double* Vi
 // kGrad: only g_p's largest entry and the cost are wanted (the gradient norm at the point a solve
 // ends on): V_p is neither summed nor stored, nothing is damped.
 template <class M, bool kStore, bool kGrad = false>
-__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
+__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int keep_v) {
     __shared__ double red[block_reduce_scratch<2>()];
     const int lane = threadIdx.x & 63;
     const Tile t = wave_tile(d);
@@ -186,11 +186,16 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda) {
         writer = key >= 0 && last == lane;
     }
     if (writer) {
-        double* Vo = d.V + 6 * (size_t)key;
+        // V_p and g_p themselves are only read back to damp again after a rejected step (and by the
+        // diagnostic entry points): inside a solve they stay in registers and the rare rejected
+        // step linearises again
+        if (keep_v) {
+            double* Vo = d.V + 6 * (size_t)key;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Vo[i] = acc[i];
-        double* go = d.gp + 4 * (size_t)key;
-        go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
+            for (int i = 0; i < 6; ++i) Vo[i] = acc[i];
+            double* go = d.gp + 4 * (size_t)key;
+            go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
+        }
         gmax = fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8])));
         if (lambda > 0.0) damp_point(d, key, acc, acc + 6, lambda);
     }
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
         key = d.pm_pt[j];
         X = d.X[key];
         if (!t.is_long) {
-            g = *reinterpret_cast<const double4*>(d.gp + 4 * (size_t)key);
+            g = d.s0[key];
             const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
             v01 = vi[0]; v23 = vi[1]; v45 = vi[2];
         }
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
         writer = lane == 0;
         if (key >= 0) {
             X = d.X[key];
-            g = *reinterpret_cast<const double4*>(d.gp + 4 * (size_t)key);
+            g = d.s0[key];
             const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
             v01 = vi[0]; v23 = vi[1]; v45 = vi[2];
         }
@@ -555,10 +560,10 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     }
     double dp[3] = {0, 0, 0};
     if (key >= 0) {
-        const double t0 = e[0] + g.x, t1 = e[1] + g.y, t2 = e[2] + g.z;
-        dp[0] = -(v01.x * t0 + v01.y * t1 + v23.x * t2);
-        dp[1] = -(v01.y * t0 + v23.y * t1 + v45.x * t2);
-        dp[2] = -(v23.x * t0 + v45.x * t1 + v45.y * t2);
+        // g holds V*^-1 g_p
+        dp[0] = -(v01.x * e[0] + v01.y * e[1] + v23.x * e[2] + g.x);
+        dp[1] = -(v01.y * e[0] + v23.y * e[1] + v45.x * e[2] + g.y);
+        dp[2] = -(v23.x * e[0] + v45.x * e[1] + v45.y * e[2] + g.z);
     }
     if (writer) {
         d.X_trial[key] = make_double4(X.x + dp[0], X.y + dp[1], X.z + dp[2], 0.0);
@@ -703,16 +708,17 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     if (d.n_obs == 0) return;
     SFMBA_LAUNCH(d, k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), st, d, jc, jp);
 }
-void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only) {
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only, bool keep_v) {
+    const int kv = keep_v || !(lambda > 0.0) ? 1 : 0;     // undamped: V and g_p are the only products
     const int nb = blocks_wtile(d);
     if (nb > 0 && grad_only) {
-        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0);
-        else hipLaunchKernelGGL((k_lin_pm<Pinhole, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0);
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0, 0);
+        else hipLaunchKernelGGL((k_lin_pm<Pinhole, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0, 0);
     } else if (nb > 0) {
-        if (d.model == MODEL_BAL && store_seeds) hipLaunchKernelGGL((k_lin_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
-        else if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
-        else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
-        else hipLaunchKernelGGL((k_lin_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda);
+        if (d.model == MODEL_BAL && store_seeds) hipLaunchKernelGGL((k_lin_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
+        else if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
+        else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
+        else hipLaunchKernelGGL((k_lin_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
     }
     hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
 }
