@@ -614,11 +614,16 @@ __global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __re
     if (threadIdx.x == 0) { put_partial(d, SLOT_STEP2_CAM, a); put_partial(d, SLOT_X2_CAM, b); }
 }
 
-// scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per slot.
-__global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, int nblocks, unsigned max_mask) {
+// scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per slot.  Two
+// runs of slots with their own partial counts can share a launch: workgroups [0, count_a) take the
+// slots from first_slot, the rest those from first_b (sums only).
+__global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, int nblocks, unsigned max_mask,
+                                                        int count_a, int first_b, int nblocks_b) {
     __shared__ double red[16];
-    const int slot = first_slot + blockIdx.x;
-    const bool is_max = (max_mask >> blockIdx.x) & 1u;
+    const bool second = (int)blockIdx.x >= count_a;
+    const int slot = second ? first_b + (int)blockIdx.x - count_a : first_slot + (int)blockIdx.x;
+    const bool is_max = !second && ((max_mask >> blockIdx.x) & 1u);
+    if (second) nblocks = nblocks_b;
     const double* part = d.scal_part + (size_t)slot * kMaxScalBlocks;
     // eight loads in flight per thread (the order of the additions is fixed all the same)
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -668,21 +673,33 @@ void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st) {
     launch_chunk_reduce(d, 2, out2, st);
 }
 
-// max |g_c| over the cameras (after the all-reduce of UG).
+// max |g_c| over the cameras (after the all-reduce of UG), straight into its scalar slot: one
+// workgroup, eight loads in flight per thread.
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_gmax_cam(Dev d) {
+__global__ __launch_bounds__(1024) void k_gmax_cam(Dev d) {
     constexpr int ND = M::ND;
     __shared__ double red[16];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = d.n_cam * ND;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024;
+            x[u] = i < n ? fabs(d.UG[M::NV * (size_t)(i / ND) + M::NU + (i % ND)]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = fmax(a[u], x[u]);
+    }
     double g = 0.0;
-    if (i < d.n_cam * ND) g = fabs(d.UG[M::NV * (size_t)(i / ND) + M::NU + (i % ND)]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) g = fmax(g, a[u]);
     const double m = block_max(g, red);
-    if (threadIdx.x == 0) put_partial(d, SLOT_GMAX_CAM, m);
+    if (threadIdx.x == 0) d.scalars[SLOT_GMAX_CAM] = m;
 }
 void launch_gmax_cam(const Dev& d, hipStream_t st) {
-    const int nb = cdiv(d.n_cam * cam_dim(d), kBlock);
-    SFMBA_LAUNCH(d, k_gmax_cam, dim3(nb), st, d);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(1), dim3(1024), 0, st, d, (int)SLOT_GMAX_CAM, nb, 1u);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_gmax_cam<Bal>), dim3(1), dim3(1024), 0, st, d);
+    else hipLaunchKernelGGL((k_gmax_cam<Pinhole>), dim3(1), dim3(1024), 0, st, d);
 }
 
 // a += b (in-process all-reduce of several handles)
@@ -720,7 +737,7 @@ void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st
         else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
         else hipLaunchKernelGGL((k_lin_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
     }
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u);
+    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u, 2, 0, 0);
 }
 void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only) {
     if (d.n_chunks == 0) return;
@@ -761,11 +778,12 @@ void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y,
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st) {
     const int nb = blocks_wtile(d);
     if (nb > 0) SFMBA_LAUNCH(d, k_back_pm, dim3(nb), st, d, dc, dp_out);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(5), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u);     // MODEL .. NONFINITE
+    // MODEL .. NONFINITE, and with them the two slots k_cam_update left as block partials
+    hipLaunchKernelGGL(k_scal_finalize, dim3(7), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u, 5, (int)SLOT_STEP2_CAM, blocks_cam(d));
 }
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st) {
+    // (its two scalar slots are finalised together with those of k_back_pm, which always follows)
     SFMBA_LAUNCH(d, k_cam_update, dim3(blocks_cam(d)), st, d, dc);
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_STEP2_CAM, blocks_cam(d), 0u);
 }
 
 }  // namespace sfmba

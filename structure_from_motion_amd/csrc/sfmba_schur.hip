@@ -16,6 +16,8 @@
 //
 // This is the camera-camera accumulation that replaces the LSMR products J v / J' u of the
 // reference's solver (scipy/optimize/_lsq/trf.py:479-480, scipy/sparse/linalg/_isolve/lsmr.py).
+#include <algorithm>
+
 #include "sfmba_internal.h"
 
 namespace sfmba {
@@ -293,7 +295,8 @@ void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const
         if (d.n_ublk > 0)
             hipLaunchKernelGGL((k_finish_offdiag<Bal::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
     } else {
-        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, tpart, f);
+        // (with the single-launch PCG the grid is widened: its threads also arm the exchange buffers)
+        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(std::max(cdiv(d.n_cam, kBlock), scaled ? 128 : 1)), dim3(kBlock), 0, st, d, lambda, tpart, f);
         if (d.n_ublk > 0)
             hipLaunchKernelGGL((k_finish_offdiag<Pinhole::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
     }
