@@ -88,8 +88,11 @@ __global__ __launch_bounds__(kBlock) void k_jacobian_blocks(Dev d, double* __res
 // observation beg + l, so every stream is read and written fully coalesced, and per-point sums
 // are segmented reductions over the lanes of a point.
 struct Tile { int beg, end; bool valid, is_long; };
-__device__ __forceinline__ Tile wave_tile(const Dev& d) {
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+// consecutive tiles one wavefront of k_lin_pm works through (1, 2, 4, 8 measured: 4 and 8 save 4 % of
+// the kernel by spreading its prologue over more work)
+constexpr int kTilesPerWave = 4;
+__device__ __forceinline__ Tile wave_tile(const Dev& d, int tpw = 1, int rep = 0) {
+    const int q = (xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6)) * tpw + rep;
     Tile t;
     t.valid = q < d.n_wtiles;
     t.beg = t.valid ? __builtin_amdgcn_readfirstlane(d.wtile_beg[q]) : 0;
@@ -130,9 +133,11 @@ template <class M, bool kStore, bool kGrad = false>
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int keep_v) {
     __shared__ double red[block_reduce_scratch<2>()];
     const int lane = threadIdx.x & 63;
-    const Tile t = wave_tile(d);
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double cost = 0.0, gmax = 0.0;
+#pragma unroll 1
+    for (int rep = 0; rep < kTilesPerWave; ++rep) {
+    const Tile t = wave_tile(d, kTilesPerWave, rep);
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int key = -1 - lane;
     for (int j = t.beg + lane; j < t.end; j += 64) {
         const int p = d.pm_pt[j];
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
             const int last = seg_last(key, lane);
             writer = key >= 0 && last == lane;
         }
-        if (writer) gmax = fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2])));
+        if (writer) gmax = fmax(gmax, fmax(fabs(g3[0]), fmax(fabs(g3[1]), fabs(g3[2]))));
         writer = false;
     } else if (t.is_long) {
 #pragma unroll
@@ -196,8 +201,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
             double* go = d.gp + 4 * (size_t)key;
             go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
         }
-        gmax = fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8])));
+        gmax = fmax(gmax, fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8]))));
         if (lambda > 0.0) damp_point(d, key, acc, acc + 6, lambda);
+    }
     }
     static_assert(SLOT_GMAX_PT == SLOT_COST + 1, "slot order");
     const double vals[2] = {cost, gmax};
@@ -516,8 +522,8 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
                                                     double* __restrict__ dp_out) {
     __shared__ double red[block_reduce_scratch<5>()];
     const int lane = threadIdx.x & 63;
-    const Tile t = wave_tile(d);
     double model = 0.0, step2 = 0.0, x2 = 0.0, trial = 0.0, bad = 0.0;
+    const Tile t = wave_tile(d);        // (several tiles per wavefront, as in k_lin_pm, measured: 3 % slower here)
     double e[3] = {0, 0, 0};
     int key = -1 - lane;
     BackObs<M> o{};
@@ -568,8 +574,8 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
     if (writer) {
         d.X_trial[key] = make_double4(X.x + dp[0], X.y + dp[1], X.z + dp[2], 0.0);
         if (dp_out) { dp_out[3 * (size_t)key] = dp[0]; dp_out[3 * (size_t)key + 1] = dp[1]; dp_out[3 * (size_t)key + 2] = dp[2]; }
-        step2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
-        x2 = X.x * X.x + X.y * X.y + X.z * X.z;
+        step2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+        x2 += X.x * X.x + X.y * X.y + X.z * X.z;
     }
     if (t.is_long) {
         for (int j = t.beg + lane; j < t.end; j += 64) {
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restr
         double u0, u1;
         M::jp_times(o.s, o.k.q, dp, u0, u1);
         const double l0 = o.ru + o.w0 + u0, l1 = o.rv + o.w1 + u1;
-        model = l0 * l0 + l1 * l1;
+        model += l0 * l0 + l1 * l1;
         trial_cost<M>(d, o, kt, X, dp, trial, bad);
     }
     static_assert(SLOT_STEP2_PT == SLOT_MODEL + 1 && SLOT_X2_PT == SLOT_MODEL + 2 && SLOT_TRIAL == SLOT_MODEL + 3 &&
@@ -727,7 +733,7 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
 }
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only, bool keep_v) {
     const int kv = keep_v || !(lambda > 0.0) ? 1 : 0;     // undamped: V and g_p are the only products
-    const int nb = blocks_wtile(d);
+    const int nb = cdiv(d.n_wtiles, (kBlock / 64) * kTilesPerWave);
     if (nb > 0 && grad_only) {
         if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0, 0);
         else hipLaunchKernelGGL((k_lin_pm<Pinhole, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0, 0);
