@@ -267,3 +267,15 @@ def test_errors():
     bad = g["camera_indices"].copy(); bad[3] = 5
     with pytest.raises(IndexError):
         make_engine(dict(g, camera_indices=bad))
+
+
+def test_per_camera_reprojection_errors():
+    g = load_golden("bal_shuffled_9_200_700")
+    with make_engine(g) as eng:
+        mean, cnt = eng.reprojection_errors()
+    f = b.fun(*b.pack(g)[0:1], *b.pack(g)[1]).reshape(-1, 2)
+    err = np.linalg.norm(f, axis=1)
+    for c in range(g["n_cameras"]):
+        sel = g["camera_indices"] == c
+        assert cnt[c] == sel.sum()
+        assert abs(mean[c] - err[sel].mean()) <= 1e-10 * err[sel].mean()
