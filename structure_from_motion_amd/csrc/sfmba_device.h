@@ -252,6 +252,7 @@ struct Pinhole {
     static constexpr int NU = 21;             // packed upper triangle of an ND x ND block
     static constexpr int NV = 27;             // NU + ND: what a chunk accumulates per camera
     static constexpr int CW = 6;              // 16-byte words of a camera record
+    static constexpr bool kDiagonalPixelMap = true;    // d pixel / d (x, y) is diagonal: jc[4] = jc[ND + 3] = 0
     using Cam = sfmba::Cam;
     struct Obs { Seed s; Intr K; };
     static __device__ __forceinline__ Cam load(const double2* __restrict__ cams, int c) { return load_cam(cams, c); }
@@ -313,6 +314,7 @@ struct Bal {
     static constexpr int NU = 45;
     static constexpr int NV = 54;
     static constexpr int CW = 8;              // q[9] t[3] f k1 k2 pad
+    static constexpr bool kDiagonalPixelMap = false;
     struct Cam { double q[9]; double t[3]; double f, k1, k2; };
     // a = d pixel / d (x, y) (symmetric 2x2), g = (r, f n, f n^2): d pixel / d (f, k1, k2) = -(x, y) g
     struct Obs { Seed s; double a00, a01, a11, g0, g1, g2, fr; };

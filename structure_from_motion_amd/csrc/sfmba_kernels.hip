@@ -254,11 +254,18 @@ __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
         double jc[2 * ND];
         M::jac_cam(ob, jc);
         if (!kGrad) {
+            // (pinhole model: jc[4] and jc[ND + 3] are zero, products with them are left out)
+            constexpr bool kZ = M::kDiagonalPixelMap;
             int n = 0;
 #pragma unroll
             for (int i = 0; i < ND; ++i)
 #pragma unroll
-                for (int j = i; j < ND; ++j) acc[n++] += jc[i] * jc[j] + jc[ND + i] * jc[ND + j];
+                for (int j = i; j < ND; ++j) {
+                    const bool no_u = kZ && (i == 4 || j == 4), no_v = kZ && (i == 3 || j == 3);
+                    if (!(no_u && no_v))
+                        acc[n] += no_u ? jc[ND + i] * jc[ND + j] : no_v ? jc[i] * jc[j] : jc[i] * jc[j] + jc[ND + i] * jc[ND + j];
+                    ++n;
+                }
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) acc[NU + i] += jc[i] * ru + jc[ND + i] * rv;
@@ -333,13 +340,16 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
         const double m00 = a[0] * ta0 + a[1] * ta1 + a[2] * ta2;
         const double m01 = a[0] * tb0 + a[1] * tb1 + a[2] * tb2;
         const double m11 = b[0] * tb0 + b[1] * tb1 + b[2] * tb2;
+        // (pinhole model: jc[4] and jc[ND + 3] are zero, products with them are left out)
+        constexpr bool kZ = M::kDiagonalPixelMap;
         int n = 0;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const double l0 = jc[i] * m00 + jc[ND + i] * m01;
-            const double l1 = jc[i] * m01 + jc[ND + i] * m11;
+            const double l0 = kZ && i == 3 ? jc[i] * m00 : kZ && i == 4 ? jc[ND + i] * m01 : jc[i] * m00 + jc[ND + i] * m01;
+            const double l1 = kZ && i == 3 ? jc[i] * m01 : kZ && i == 4 ? jc[ND + i] * m11 : jc[i] * m01 + jc[ND + i] * m11;
 #pragma unroll
-            for (int j = i; j < ND; ++j) acc[n++] += l0 * jc[j] + l1 * jc[ND + j];
+            for (int j = i; j < ND; ++j)
+                acc[n++] += kZ && j == 3 ? l0 * jc[j] : kZ && j == 4 ? l1 * jc[ND + j] : l0 * jc[j] + l1 * jc[ND + j];
         }
         // Jc' (Jp (Vinv g_p)): the right-hand-side contribution
         const double w0 = a[0] * s0.x + a[1] * s0.y + a[2] * s0.z;

@@ -70,12 +70,16 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
         double jca[2 * ND], jcb[2 * ND];
         M::jac_cam(oa, jca);
         M::jac_cam(ob, jcb);
+        // (with the pinhole model column 3 of a camera block, the x translation, has no v entry and
+        // column 4 no u entry: products with those zeros are left out)
+        constexpr bool kZ = M::kDiagonalPixelMap;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const double l0 = jca[i] * m00 + jca[ND + i] * m10;
-            const double l1 = jca[i] * m01 + jca[ND + i] * m11;
+            const double l0 = kZ && i == 3 ? jca[i] * m00 : kZ && i == 4 ? jca[ND + i] * m10 : jca[i] * m00 + jca[ND + i] * m10;
+            const double l1 = kZ && i == 3 ? jca[i] * m01 : kZ && i == 4 ? jca[ND + i] * m11 : jca[i] * m01 + jca[ND + i] * m11;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) acc[ND * i + j] += l0 * jcb[j] + l1 * jcb[ND + j];
+            for (int j = 0; j < ND; ++j)
+                acc[ND * i + j] += kZ && j == 3 ? l0 * jcb[j] : kZ && j == 4 ? l1 * jcb[ND + j] : l0 * jcb[j] + l1 * jcb[ND + j];
         }
     }
     constexpr int kPasses = (NN + 17) / 18;
