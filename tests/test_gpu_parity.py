@@ -371,3 +371,18 @@ def test_gtol_termination_is_the_same_with_and_without_the_iteration_table(solve
             res.append((st.status, st.iterations, st.accepted, st.nfev, st.njev, st.final_cost, st.optimality))
     assert res[0][0] == 1 and res[0][6] < 10.0 * opt
     assert res[0] == res[1]
+
+
+def test_host_thread_count_of_the_setup_does_not_change_the_result(monkeypatch):
+    # the sorts and pair lists of sfmba_set_problem are built on several host threads above
+    # 200 000 observations: the layout, hence every sum, must not depend on how many
+    g = syn.make_shape("venice", seed=4, scale=0.06)
+    assert g["n_obs"] > 200000
+    out = []
+    for nt in ("1", "7"):
+        monkeypatch.setenv("SFMBA_THREADS", nt)
+        with make_engine(g) as eng:
+            st = eng.solve()
+            out.append((st.final_cost, st.iterations, st.pcg_iterations) + eng.get_params())
+    assert out[0][:3] == out[1][:3]
+    assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
