@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--linear-solver", type=int, default=0, help="0 auto, 1 PCG, 2 dense Cholesky")
     ap.add_argument("--schur-mode", type=int, default=0, help="0 auto, 1 implicit, 2 explicit")
     ap.add_argument("--pcg-mode", type=int, default=0, help="0 auto, 1 two launches per iteration, 2 single launch")
+    ap.add_argument("--pcg-coarse", type=int, default=0,
+                    help="two-level PCG preconditioner: 0 default policy, -1 off, k clusters of k cameras")
     ap.add_argument("--camera-model", default="pinhole", choices=("pinhole", "bal"),
                     help="pinhole: the 12-number camera of bundle_adjustment.py (the headline workload); "
                          "bal: the 9-number camera of ba_test.py on the same scene")
@@ -117,7 +119,7 @@ def main():
         p["K"] = None
     else:
         p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
-    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode,
+    solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode, pcg_coarse=args.pcg_coarse,
                        camera_model=args.camera_model)
     eng = Engine(device=local_rank, rank=rank, nranks=world, **solver_opts)
     t0 = time.time()
@@ -237,7 +239,9 @@ def main():
                        "parallelism": f"point-partitioned x{world}" if world > 1 else "single GPU",
                        "linear_solver": {1: "pcg", 2: "dense-cholesky"}[last.linear_solver],
                        "schur_mode": {1: "implicit", 2: "explicit"}[last.schur_mode],
-                       "pcg": "single launch" if last.pcg_single_launch else "launch per iteration"},
+                       "pcg": "single launch" if last.pcg_single_launch else "launch per iteration",
+                       "pcg_preconditioner": (f"block-Jacobi + coarse space of {last.pcg_coarse_dim} in {last.pcg_coarse_solves} "
+                                              f"of {last.iterations} solves") if last.pcg_coarse_solves else "block-Jacobi"},
             "lm_iters_per_sec": iters / elapsed,
             "lm_iterations_per_solve": iters / args.steps,
             "pcg_iterations_per_solve": sum(s.pcg_iterations for s in stats) / args.steps,

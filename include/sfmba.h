@@ -83,6 +83,17 @@ typedef struct sfmba_options {
     int32_t pcg_mode;
     int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
     int32_t camera_model;     /* enum sfmba_camera_model; default SFMBA_CAMERA_PINHOLE */
+    /* Two-level preconditioner of the launch-per-iteration PCG on the explicit matrix (pcg_mode 1,
+     * and whatever pcg_mode 0 resolves to when the single-launch solver does not apply): next to
+     * the block-Jacobi blocks, a coarse space of seven vectors (translation, rotation, scale of
+     * the world) per cluster of consecutive cameras, M^-1 = M_J^-1 + Z (Z'SZ)^-1 Z'.
+     *   0 = choose: built for 256 cameras and more, clusters of 128; a solve uses it once an
+     *       earlier solve of the same sfmba_solve took 24 iterations or more;
+     *  -1 = never;
+     *   k > 0 = clusters of k cameras (at least 48; raised where 7 n_cameras / k would exceed 4096),
+     *       used from the first solve on; selects pcg_mode 1.
+     * n_cl = max(1, n_cameras / k) clusters, cluster i = cameras [i n_cameras / n_cl, (i+1) n_cameras / n_cl). */
+    int32_t pcg_coarse;
 } sfmba_options;
 
 /* Camera models.  D = tangent numbers per camera (width of a Jacobian block and of every
@@ -127,6 +138,8 @@ typedef struct sfmba_stats {
     int64_t schur_chunks;                      /* wavefront-sized pair chunks per assembly */
     int64_t pcg_single_launch;                 /* linear solves done by the single-launch PCG */
     int64_t pcg_single_fallbacks;              /* single-launch solves redone launch by launch */
+    int64_t pcg_coarse_solves;                 /* linear solves preconditioned with the coarse space */
+    int64_t pcg_coarse_dim;                    /* coarse unknowns (7 x clusters), 0 = no coarse space built */
 } sfmba_stats;
 
 /* Fill *opts with the defaults listed above. */
@@ -219,6 +232,12 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y);
 /* Reduced right-hand side b = -g_cam + sum W V*^-1 g_pt and inverse of the block-Jacobi
  * preconditioner blocks (n_cameras x 36).  Either may be NULL. */
 int sfmba_get_reduced(sfmba_handle* h, double* rhs, double* precond_inv);
+/* z = M^-1 r with the preconditioner the launch-per-iteration PCG would use at the current
+ * linearisation, r and z n_cameras x 6: the block-Jacobi blocks, plus the coarse correction
+ * Z (Z'SZ)^-1 Z' r when the handle has a coarse space (options.pcg_coarse); *coarse_dim then
+ * receives 7 x clusters, otherwise 0.  (No counterpart in the reference: LSMR there runs
+ * unpreconditioned on the column-scaled Jacobian.) */
+int sfmba_precondition(sfmba_handle* h, const double* r, double* z, int32_t* coarse_dim);
 /* Solve the damped normal equations for the step at the current linearisation:
  * step_cam n_cameras x 6, step_pt n_points x 3; *pcg_iters receives the iteration count. */
 int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t* pcg_iters);

@@ -8,14 +8,16 @@ shape, takes the reduced system of the fifth through the diagnostic entry points
     consecutive cameras, M^-1 = M_J^-1 + Z (Z'SZ)^-1 Z'.
 Measured on one MI355X: 141 iterations -> 17 / 10 / 6 with clusters of 64 / 32 / 16 cameras
 (coarse dimensions 196 / 392 / 784).
-Usage: python profiles/study_two_level_pcg.py"""
+Usage: python profiles/study_two_level_pcg.py [shape [cluster sizes ...]]"""
 import sys, time
 import numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from structure_from_motion_amd import synthetic as syn
 from structure_from_motion_amd.engine import Engine
-p = syn.make_shape("venice", seed=0)
+SHAPE = sys.argv[1] if len(sys.argv) > 1 else "venice"
+CLUSTERS = [int(a) for a in sys.argv[2:]] or [64, 32, 16]
+p = syn.make_shape(SHAPE, seed=0)
 with Engine(max_iterations=4) as eng:
     eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
     st = eng.solve()
@@ -57,12 +59,15 @@ with Engine(max_iterations=4) as eng:
     Qv, _ = np.linalg.qr(V)
     P = lambda v: v - Qv @ (Qv.T @ v)
     print("gauge share of b:", float(np.linalg.norm(Qv.T @ bb) / np.linalg.norm(bb)), " of x:", float(np.linalg.norm(Qv.T @ x0) / np.linalg.norm(x0)), flush=True)
-    for k in (64, 32, 16):
+    def quality(x): return float(np.linalg.norm(S(x) - bb) / np.linalg.norm(bb)), float(0.5 * x @ S(x) - bb @ x)
+    print("plain PCG: relative residual, model value:", quality(x0), flush=True)
+    for k, cols in [(k, cols) for k in CLUSTERS for cols in ((0, 1, 2, 3, 4, 5, 6), (0, 1, 2, 6), (0, 1, 2))]:
         ncl = (nc + k - 1) // k
-        Z = np.zeros((6 * nc, 7 * ncl))
+        nv = len(cols)
+        Z = np.zeros((6 * nc, nv * ncl))
         for c in range(ncl):
             rows = slice(6 * c * k, 6 * min((c + 1) * k, nc))
-            Z[rows, 7 * c:7 * c + 7] = V[rows]
+            Z[rows, nv * c:nv * c + nv] = V[rows][:, cols]
         Z /= np.linalg.norm(Z, axis=0)
         t0 = time.time()
         SZ = np.stack([S(Z[:, j].copy()) for j in range(Z.shape[1])], axis=1)
@@ -77,4 +82,4 @@ with Engine(max_iterations=4) as eng:
                 pdir = z + (rzn / rz) * pdir; rz = rzn
             return maxit, x
         it, x = pcg2(bb)
-        print(f"two-level, clusters of {k} cameras (coarse dimension {Z.shape[1]}): {it} iterations (setup {time.time()-t0:.1f}s)", flush=True)
+        print(f"two-level, clusters of {k} cameras, vectors {cols} (coarse dimension {Z.shape[1]}): {it} iterations, residual/model {quality(x)} (setup {time.time()-t0:.1f}s)", flush=True)

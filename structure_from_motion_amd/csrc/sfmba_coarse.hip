@@ -1,0 +1,312 @@
+// Coarse space of the two-level PCG preconditioner (gfx950, fp64).
+//
+// Block-Jacobi alone leaves the error components that move whole groups of cameras together: the
+// reduced camera matrix S is nearly singular along the seven gauge directions (translation,
+// rotation and scale of the whole scene), and restricted to a group of neighbouring cameras those
+// directions are the slowest modes of the iteration.  The two-level preconditioner adds a
+// correction on exactly that space,
+//
+//     M^-1 = M_J^-1 + Z E^-1 Z',        E = Z' S Z,
+//
+// where Z has seven columns per cluster of consecutive cameras: the change of every camera of the
+// cluster under a unit translation (3), rotation (3) and scaling (1) of the world, written in the
+// camera tangent (dw, dt, ...) of the left perturbation Y' = exp([dw]x) Y + dt that the Jacobian
+// blocks use.  For a camera with rotation Q and translation t:
+//     world translation e_a :  dw = 0,          dt = -Q e_a
+//     world rotation    e_k :  dw = -Q e_k,     dt = (Q e_k) x t
+//     world scaling         :  dw = 0,          dt = t
+// (intrinsic entries of the tangent, where the camera model has any, are zero).  E is small
+// (7 x clusters) and dense; it is assembled from the block-CSR matrix once per damping, scaled to
+// unit diagonal and inverted in place by a blocked Gauss-Jordan sweep, one launch per 32 columns.
+// Each PCG iteration then costs two more small launches: the restriction Z' r and the
+// prolongation z += Z E^-1 (Z' r), which also takes over the r'z partials from k_pcg_update.
+// All sums run in a fixed order, so the result is the same from run to run.
+#include "sfmba_internal.h"
+
+namespace sfmba {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+constexpr int kVecs = kCoarseVecs;            // coarse vectors per cluster
+constexpr int kSlotsOf7 = kBlock / kVecs;     // 36 groups of 7 threads in a workgroup
+constexpr int kTile = 32;                     // Gauss-Jordan block size
+
+// Z of every camera, [n_cam][7][ND]; thread = camera.
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_coarse_basis(Dev d, Coarse k) {
+    constexpr int ND = M::ND;
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= d.n_cam) return;
+    const auto cam = M::load(d.cams, c);
+    double z[kVecs * ND];
+#pragma unroll
+    for (int i = 0; i < kVecs * ND; ++i) z[i] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double u0 = cam.q[a], u1 = cam.q[3 + a], u2 = cam.q[6 + a];     // Q e_a
+        z[a * ND + 3] = -u0; z[a * ND + 4] = -u1; z[a * ND + 5] = -u2;
+        z[(3 + a) * ND + 0] = -u0; z[(3 + a) * ND + 1] = -u1; z[(3 + a) * ND + 2] = -u2;
+        z[(3 + a) * ND + 3] = u1 * cam.t[2] - u2 * cam.t[1];
+        z[(3 + a) * ND + 4] = u2 * cam.t[0] - u0 * cam.t[2];
+        z[(3 + a) * ND + 5] = u0 * cam.t[1] - u1 * cam.t[0];
+    }
+    z[6 * ND + 3] = cam.t[0]; z[6 * ND + 4] = cam.t[1]; z[6 * ND + 5] = cam.t[2];
+    double* out = k.Z + kVecs * ND * (size_t)c;
+#pragma unroll
+    for (int i = 0; i < kVecs * ND; ++i) out[i] = z[i];
+}
+
+// E(I, J) = sum over the blocks (r, c) of S with r in cluster I, c in cluster J of Z_r' S_rc Z_c.
+// The blocks of a cluster pair are cut into chunks; one workgroup per chunk: a group of 7 threads
+// takes every 36th block of the chunk (thread a of the group forms row a of the 7 x 7 product),
+// the 36 partial products are added in order into the chunk's partial, and k_coarse_collect adds
+// the chunk partials of every pair in order.
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_coarse_assemble(Dev d, Coarse k) {
+    constexpr int NN = ND * ND;
+    __shared__ double part[kSlotsOf7][kVecs * kVecs];
+    const int p = blockIdx.x;
+    const int slot = threadIdx.x / kVecs, a = threadIdx.x - kVecs * slot;
+    if (slot < kSlotsOf7) {
+        double acc[kVecs];
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) acc[j] = 0.0;
+        const int e1 = k.cchunk_beg[p + 1];
+        for (int idx = k.cchunk_beg[p] + slot; idx < e1; idx += kSlotsOf7) {
+            const int b = k.cpair_blk[idx], r = k.cpair_row[idx], c = d.bsr_col[b];
+            const double* __restrict__ S = d.Sfull + NN * (size_t)b;
+            const double* __restrict__ zr = k.Z + (kVecs * (size_t)r + a) * ND;
+            const double* __restrict__ zc = k.Z + kVecs * ND * (size_t)c;
+            double u[ND];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) u[j] = 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const double zi = zr[i];
+#pragma unroll
+                for (int j = 0; j < ND; ++j) u[j] += zi * S[ND * i + j];
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < kVecs; ++a2) {
+                double g = 0.0;
+#pragma unroll
+                for (int j = 0; j < ND; ++j) g += u[j] * zc[a2 * ND + j];
+                acc[a2] += g;
+            }
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < kVecs; ++a2) part[slot][kVecs * a + a2] = acc[a2];
+    }
+    __syncthreads();
+    if (threadIdx.x < kVecs * kVecs) {
+        double s = 0.0;
+        for (int q = 0; q < kSlotsOf7; ++q) s += part[q][threadIdx.x];
+        k.cpart[kVecs * kVecs * (size_t)p + threadIdx.x] = s;
+    }
+}
+
+// thread = (cluster pair, entry of its 7 x 7 block)
+__global__ __launch_bounds__(kBlock) void k_coarse_collect(Coarse k, double* __restrict__ E) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int p = t / (kVecs * kVecs), e = t - kVecs * kVecs * p;
+    if (p >= k.n_cpairs) return;
+    double s = 0.0;
+    for (int q = k.cpair_cptr[p]; q < k.cpair_cptr[p + 1]; ++q) s += k.cpart[kVecs * kVecs * (size_t)q + e];
+    const int ra = e / kVecs, ca = e - kVecs * ra;
+    E[(size_t)(kVecs * k.cpair_i[p] + ra) * k.n_pad + kVecs * k.cpair_j[p] + ca] = s;
+}
+
+// dst = D src D with D = diag(src)^-1/2 (unit diagonal), identity on the padding and wherever a
+// diagonal entry is not positive (that coarse vector then drops out); D goes to k.scale.
+__global__ __launch_bounds__(kBlock) void k_coarse_scale(Coarse k, const double* __restrict__ src, double* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t total = (size_t)k.n_pad * k.n_pad;
+    if (idx >= total) return;
+    const int i = (int)(idx / k.n_pad), j = (int)(idx - (size_t)i * k.n_pad);
+    double si = 0.0, sj = 0.0;
+    if (i < k.n) { const double v = src[(size_t)i * k.n_pad + i]; if (v > 0.0 && v < 1e300) si = 1.0 / sqrt(v); }
+    if (j < k.n) { const double v = src[(size_t)j * k.n_pad + j]; if (v > 0.0 && v < 1e300) sj = 1.0 / sqrt(v); }
+    double v = (si != 0.0 && sj != 0.0) ? src[idx] * si * sj : 0.0;
+    if (i == j && si == 0.0) v = 1.0;
+    dst[idx] = v;
+    if (j == 0) k.scale[i] = si;
+}
+
+// One block column of the Gauss-Jordan sweep that turns a matrix into its inverse: with pivot
+// block p and P = A_pp^-1,
+//     A_pp <- P,   A_pj <- P A_pj,   A_ip <- -A_ip P,   A_ij <- A_ij - A_ip P A_pj    (i, j != p).
+// One workgroup per 32 x 32 tile; it reads `src` and writes `dst`, so no tile sees a value of this
+// step.  Every workgroup inverts the pivot block itself (in LDS, unpivoted: the matrix is
+// symmetric positive definite with unit diagonal), which is cheaper than a launch of its own.
+__global__ __launch_bounds__(kBlock) void k_coarse_gj(const double* __restrict__ src, double* __restrict__ dst, int n_pad, int p) {
+    __shared__ double P[kTile][kTile + 1], A[kTile][kTile + 1], B[kTile][kTile + 1], T[kTile][kTile + 1];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x / kTile;      // 8 rows of 32 threads
+    const bool row_p = bi == p, col_p = bj == p;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int i = ty + 8 * m;
+        P[i][tx] = src[(size_t)(kTile * p + i) * n_pad + kTile * p + tx];
+        if (!row_p) A[i][tx] = src[(size_t)(kTile * bi + i) * n_pad + kTile * p + tx];
+        if (!col_p) B[i][tx] = src[(size_t)(kTile * p + i) * n_pad + kTile * bj + tx];
+    }
+    for (int kk = 0; kk < kTile; ++kk) {
+        __syncthreads();
+        const double pv = P[kk][kk];
+        const double piv = (pv > 1e-300 && pv < 1e300) ? 1.0 / pv : 0.0;
+        const double rowk = P[kk][tx];
+        double colv[4], old[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { colv[m] = P[ty + 8 * m][kk]; old[m] = P[ty + 8 * m][tx]; }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int i = ty + 8 * m;
+            double v;
+            if (i == kk) v = tx == kk ? piv : rowk * piv;
+            else v = tx == kk ? -colv[m] * piv : old[m] - colv[m] * piv * rowk;
+            P[i][tx] = v;
+        }
+    }
+    __syncthreads();
+    double out[4];
+    if (row_p && col_p) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) out[m] = P[ty + 8 * m][tx];
+    } else if (row_p) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int q = 0; q < kTile; ++q) s += P[ty + 8 * m][q] * B[q][tx];
+            out[m] = s;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int q = 0; q < kTile; ++q) s += A[ty + 8 * m][q] * P[q][tx];
+            T[ty + 8 * m][tx] = s;
+            out[m] = -s;
+        }
+        if (!col_p) {
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double s = src[(size_t)(kTile * bi + ty + 8 * m) * n_pad + kTile * bj + tx];
+#pragma unroll 8
+                for (int q = 0; q < kTile; ++q) s -= T[ty + 8 * m][q] * B[q][tx];
+                out[m] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dst[(size_t)(kTile * bi + ty + 8 * m) * n_pad + kTile * bj + tx] = out[m];
+}
+
+// rc = D Z' r: one workgroup per cluster; a group of 7 threads takes every 36th camera.
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_coarse_restrict(Dev d, Coarse k, int state) {
+    __shared__ double part[kSlotsOf7][kVecs];
+    if (d.pcg[state].done) return;
+    const int I = blockIdx.x;
+    const int slot = threadIdx.x / kVecs, a = threadIdx.x - kVecs * slot;
+    if (slot < kSlotsOf7) {
+        double acc = 0.0;
+        const int hi = k.cl_ptr[I + 1];
+        for (int c = k.cl_ptr[I] + slot; c < hi; c += kSlotsOf7) {
+            const double* __restrict__ z = k.Z + (kVecs * (size_t)c + a) * ND;
+            const double* __restrict__ r = d.pr + ND * (size_t)c;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) s += z[i] * r[i];
+            acc += s;
+        }
+        part[slot][a] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < kVecs) {
+        double s = 0.0;
+        for (int q = 0; q < kSlotsOf7; ++q) s += part[q][threadIdx.x];
+        const int g = kVecs * I + threadIdx.x;
+        k.rc[g] = k.scale[g] * s;
+    }
+}
+
+// z += Z D Einv rc and the r'z partials; thread = (camera, row) as in k_pcg_update.  A workgroup's
+// cameras lie in at most two clusters (a cluster is never smaller than a workgroup's share of
+// cameras): it forms the up to 14 entries of y = D Einv rc it needs itself, one wavefront per row.
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int state) {
+    constexpr int kCams = kBlock / ND;
+    __shared__ double red[16];
+    __shared__ double y[2 * kVecs];
+    if (d.pcg[state].done) return;
+    const int c0 = blockIdx.x * kCams;
+    const int c1 = min(c0 + kCams, d.n_cam) - 1;
+    const int I0 = k.cam_cl[c0];
+    const int nrows = min(kVecs * (k.cam_cl[c1] - I0 + 1), 2 * kVecs);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int row = w; row < nrows; row += kBlock / 64) {
+        const int g = kVecs * I0 + row;
+        const double* __restrict__ e = k.Einv + (size_t)g * k.n_pad;
+        double s = 0.0;
+        for (int j = lane; j < k.n_pad; j += 64) s += e[j] * k.rc[j];
+        s = wave_sum(s);
+        if (lane == 0) y[row] = k.scale[g] * s;
+    }
+    __syncthreads();
+    const int local = threadIdx.x / ND, kk = threadIdx.x - ND * local;
+    const int c = c0 + local;
+    double dot = 0.0;
+    if (local < kCams && c < d.n_cam) {
+        const size_t o = ND * (size_t)c + kk;
+        const double* __restrict__ zc = k.Z + kVecs * ND * (size_t)c + kk;
+        const double* yy = y + kVecs * (k.cam_cl[c] - I0);
+        double z = d.pz[o];
+#pragma unroll
+        for (int a = 0; a < kVecs; ++a) z += zc[a * ND] * yy[a];
+        d.pz[o] = z;
+        dot = d.pr[o] * z;
+    }
+    const double s = block_sum(dot, red);
+    if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
+}
+
+// ---- launch wrappers --------------------------------------------------------------------
+
+// Builds Z, E = Z'SZ and its inverse; returns the buffer that holds D^-1 E^-1 D^-1 (k.scale = D).
+const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st) {
+    const dim3 blk(kBlock);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_basis<Bal>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
+    else hipLaunchKernelGGL((k_coarse_basis<Pinhole>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
+    const size_t total = (size_t)k.n_pad * k.n_pad;
+    (void)hipMemsetAsync(k.E[0], 0, total * sizeof(double), st);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_assemble<Bal::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);
+    else hipLaunchKernelGGL((k_coarse_assemble<Pinhole::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);
+    hipLaunchKernelGGL(k_coarse_collect, dim3(cdiv(k.n_cpairs * kVecs * kVecs, kBlock)), blk, 0, st, k, k.E[0]);
+    hipLaunchKernelGGL(k_coarse_scale, dim3((unsigned)((total + kBlock - 1) / kBlock)), blk, 0, st, k, k.E[0], k.E[1]);
+    int src = 1;
+    const int nt = k.n_pad / kTile;
+    for (int p = 0; p < nt; ++p) {
+        hipLaunchKernelGGL(k_coarse_gj, dim3(nt, nt), blk, 0, st, k.E[src], k.E[src ^ 1], k.n_pad, p);
+        src ^= 1;
+    }
+    return k.E[src];
+}
+
+// z = M_J^-1 r is in pz and r in pr: adds the coarse correction and rewrites the r'z partials.
+// `state` names the PcgState whose `done` flag gates the work.
+void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st) {
+    const dim3 blk(kBlock);
+    if (d.model == MODEL_BAL) {
+        hipLaunchKernelGGL((k_coarse_restrict<Bal::ND>), dim3(k.n_cl), blk, 0, st, d, k, state);
+        hipLaunchKernelGGL((k_coarse_prolong<Bal::ND>), dim3(pcg_update_blocks(d)), blk, 0, st, d, k, state);
+    } else {
+        hipLaunchKernelGGL((k_coarse_restrict<Pinhole::ND>), dim3(k.n_cl), blk, 0, st, d, k, state);
+        hipLaunchKernelGGL((k_coarse_prolong<Pinhole::ND>), dim3(pcg_update_blocks(d)), blk, 0, st, d, k, state);
+    }
+}
+
+}  // namespace sfmba

@@ -248,6 +248,17 @@ struct sfmba_handle {
     DBuf<double2> fdots;
     bool trace_pcg = false;
     FusedPcg fused{};
+    // two-level preconditioner of the launch-per-iteration PCG on the explicit matrix
+    bool coarse_built = false;   // cluster structure and buffers present
+    bool coarse_forced = false;  // asked for: in use from the first solve on
+    bool coarse_on = false;      // the next solve uses it
+    bool coarse_failed = false;  // a solve with it did not converge: not used again in this sfmba_solve
+    bool coarse_valid = false;   // E^-1 belongs to the matrix in Sfull
+    int64_t coarse_solves = 0;
+    int coarse_from = 0;         // switched on after a solve of this many iterations
+    DBuf<int> cl_ptr, cam_cl, cpair_i, cpair_j, cpair_cptr, cchunk_beg, cpair_blk, cpair_row;
+    DBuf<double> cZ, cE[2], cscale, crc, cpart;
+    Coarse coarse{};
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
     bool dense_allowed = false;  // small enough for the dense fallback
@@ -469,6 +480,7 @@ void phase_damp(H* h, double lambda) {
             launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
             h->fused_armed = h->fused_pcg;
         }
+        h->coarse_valid = false;
     } else {
         Scope t(h, F_DAMP);
         if (h->damped_lambda != lambda) damp_points(h, lambda);
@@ -498,6 +510,10 @@ void schur_product(H* h, const double* x, const PcgState* state) {
     }
     allreduce(h, h->qS.p, (size_t)h->n_cam * h->cd);
 }
+
+// The launch-per-iteration PCG switches the coarse space on once a solve has taken this many
+// iterations: below that the set-up (assembly and inversion of E) costs more than it saves.
+constexpr int kCoarseFromIterations = 24;
 
 // Block-Jacobi PCG on S dc = rhs; result in px.  Returns the iteration count.
 PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
@@ -543,9 +559,17 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         if (st.pad == 0) { h->fused_solves++; return st; }
         h->fused_fallbacks++;
     }
+    // two-level preconditioner: the coarse matrix belongs to one damping of one linearisation
+    const bool two_level = h->explicit_schur && h->coarse_built && h->coarse_on;
+    if (two_level && !h->coarse_valid) {
+        Scope t(h, F_SCHUR);
+        h->coarse.Einv = launch_coarse_setup(h->dev, h->coarse, h->stream);
+        h->coarse_valid = true;
+    }
     {
         Scope t(h, F_PCGVEC);
         launch_pcg_init(h->dev, tol, max_iter, h->stream);
+        if (two_level) launch_coarse_apply(h->dev, h->coarse, 0, h->stream);
     }
     // Iterations are queued in batches; the state of batch k is copied to pinned host memory
     // behind it and only read after batch k+1 has been queued, so the GPU never waits for the
@@ -571,6 +595,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
             }
             Scope t(h, F_PCGVEC);
             launch_pcg_update(h->dev, cur, n_pq, h->stream);
+            if (two_level) launch_coarse_apply(h->dev, h->coarse, cur ^ 1, h->stream);
             cur ^= 1;
             ++queued;
         }
@@ -588,6 +613,18 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         if (st.done || queued >= max_iter + 2 * batch) break;
         if (!pipelined) queue_batch(slot);
         else slot ^= 1;
+    }
+    if (two_level) {
+        h->coarse_solves++;
+        if (!(st.rz <= st.tol2 * st.rz0)) {
+            // did not converge (or produced a NaN): the coarse matrix was too ill-conditioned to
+            // invert; this solve and the rest of the run use the block-Jacobi blocks alone
+            h->coarse_on = false;
+            h->coarse_failed = true;
+            return phase_pcg(h, lambda, allow_fused);
+        }
+    } else if (h->explicit_schur && h->coarse_built && !h->coarse_failed && st.iter >= h->coarse_from) {
+        h->coarse_on = true;        // solves only get longer as the damping falls
     }
     return st;
 }
@@ -710,6 +747,7 @@ void do_solve(H* h, sfmba_stats* out) {
     h->dense_fallbacks = 0;
     h->fused_solves = h->fused_fallbacks = 0;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
+    h->coarse_on = h->coarse_forced; h->coarse_failed = false; h->coarse_solves = 0;
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
     auto t0 = std::chrono::steady_clock::now();
@@ -834,6 +872,8 @@ void do_solve(H* h, sfmba_stats* out) {
     st.schur_chunks = h->explicit_schur ? h->n_pchunks : 0;
     st.ms_pairs = h->fam_ms[F_PAIRS]; st.n_pairs = h->fam_n[F_PAIRS];
     st.pcg_single_launch = h->fused_solves; st.pcg_single_fallbacks = h->fused_fallbacks;
+    st.pcg_coarse_solves = h->coarse_solves;
+    st.pcg_coarse_dim = h->explicit_schur && h->coarse_built ? h->coarse.n : 0;
     if (o.verbose >= 1 && o.rank <= 0) {
         static const char* msg[] = {"The maximum number of function evaluations is exceeded.",
                                     "`gtol` termination condition is satisfied.",
@@ -1175,6 +1215,9 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     // single-launch PCG: one workgroup per compute unit at most, every workgroup co-resident
     int pcg_mode = h->opt.pcg_mode;
     if (const char* e = getenv("SFMBA_PCG_MODE")) pcg_mode = atoi(e);
+    int coarse = h->opt.pcg_coarse;
+    if (const char* e = getenv("SFMBA_PCG_COARSE")) coarse = atoi(e);
+    if (coarse > 0) pcg_mode = 1;           // the coarse space belongs to the launch-per-iteration solver
     h->fused_pcg = false;
     if (pcg_mode != 1 && !want_dense && h->model == MODEL_PINHOLE) {     // (written for 6x6 blocks)
         const int cap = pcg_fused_max_blocks(h->device);
@@ -1209,6 +1252,73 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
             h->fused_pcg = true;
             h->fused_refused = false;
         }
+    }
+    // Coarse space of the two-level preconditioner: clusters of consecutive cameras, never smaller
+    // than the cameras one workgroup of the vector kernels handles (k_coarse_prolong relies on it)
+    // and large enough that the dense coarse matrix stays below 4096 x 4096.
+    h->coarse_built = false; h->coarse_forced = false; h->coarse_on = false; h->coarse_valid = false;
+    if (coarse >= 0 && !want_dense && !h->fused_pcg && (coarse > 0 || n_cam >= 256)) {
+        int k = coarse > 0 ? std::max(coarse, 48) : 128;
+        k = std::max(k, (int)((7LL * n_cam + 4095) / 4096));
+        const int n_cl = std::max(1, n_cam / k);
+        std::vector<int> cl_ptr((size_t)n_cl + 1), cam_cl((size_t)n_cam);
+        for (int i = 0; i <= n_cl; ++i) cl_ptr[i] = (int)((int64_t)i * n_cam / n_cl);
+        for (int i = 0; i < n_cl; ++i)
+            for (int c = cl_ptr[i]; c < cl_ptr[i + 1]; ++c) cam_cl[c] = i;
+        // blocks of the matrix grouped by cluster pair (stable counting sort)
+        std::vector<int> brow((size_t)nnzb), count((size_t)n_cl * n_cl + 1, 0);
+        for (int r = 0; r < n_cam; ++r)
+            for (int b = bsr_ptr[r]; b < bsr_ptr[r + 1]; ++b) {
+                brow[b] = r;
+                count[(size_t)cam_cl[r] * n_cl + cam_cl[bsr_col[b]] + 1]++;
+            }
+        std::vector<int> cp_i, cp_j, cp_ptr, slot_of((size_t)n_cl * n_cl, -1);
+        for (size_t key = 0; key < (size_t)n_cl * n_cl; ++key)
+            if (count[key + 1] > 0) {
+                slot_of[key] = (int)cp_i.size();
+                cp_i.push_back((int)(key / n_cl)); cp_j.push_back((int)(key % n_cl));
+                cp_ptr.push_back(0);
+            }
+        cp_ptr.push_back(0);
+        for (size_t key = 0; key < (size_t)n_cl * n_cl; ++key)
+            if (slot_of[key] >= 0) cp_ptr[slot_of[key] + 1] = count[key + 1];
+        for (size_t i = 1; i < cp_ptr.size(); ++i) cp_ptr[i] += cp_ptr[i - 1];
+        std::vector<int> fill(cp_ptr.begin(), cp_ptr.end() - 1), cp_blk((size_t)nnzb), cp_row((size_t)nnzb);
+        for (int b = 0; b < nnzb; ++b) {
+            const int sl = slot_of[(size_t)cam_cl[brow[b]] * n_cl + cam_cl[bsr_col[b]]];
+            cp_blk[fill[sl]] = b; cp_row[fill[sl]] = brow[b]; fill[sl]++;
+        }
+        // chunks of the pairs' block lists: 8 blocks per group of 7 threads
+        const int cchunk = 288;
+        std::vector<int> cp_cptr, cc_beg;
+        for (size_t q = 0; q + 1 < cp_ptr.size(); ++q) {
+            cp_cptr.push_back((int)cc_beg.size());
+            for (int b = cp_ptr[q]; b < cp_ptr[q + 1]; b += cchunk) cc_beg.push_back(b);
+        }
+        cp_cptr.push_back((int)cc_beg.size());
+        cc_beg.push_back(nnzb);
+        Coarse& k7 = h->coarse;
+        k7.n_cchunks = (int)cc_beg.size() - 1;
+        h->cpair_cptr.upload(cp_cptr, st); h->cchunk_beg.upload(cc_beg, st);
+        h->cpart.alloc((size_t)k7.n_cchunks * kCoarseVecs * kCoarseVecs);
+        k7.n_cl = n_cl; k7.n = kCoarseVecs * n_cl; k7.n_pad = (k7.n + 31) / 32 * 32; k7.n_cpairs = (int)cp_i.size();
+        h->cl_ptr.upload(cl_ptr, st); h->cam_cl.upload(cam_cl, st);
+        h->cpair_i.upload(cp_i, st); h->cpair_j.upload(cp_j, st);
+        h->cpair_blk.upload(cp_blk, st); h->cpair_row.upload(cp_row, st);
+        h->cZ.alloc((size_t)n_cam * kCoarseVecs * h->cd);
+        for (auto& e : h->cE) e.alloc((size_t)k7.n_pad * k7.n_pad);
+        h->cscale.alloc((size_t)k7.n_pad); h->crc.alloc((size_t)k7.n_pad);
+        h->crc.zero(st);
+        HIP_TRY(hipStreamSynchronize(st));
+        k7.cl_ptr = h->cl_ptr.p; k7.cam_cl = h->cam_cl.p; k7.cpair_i = h->cpair_i.p; k7.cpair_j = h->cpair_j.p;
+        k7.cpair_cptr = h->cpair_cptr.p; k7.cchunk_beg = h->cchunk_beg.p; k7.cpart = h->cpart.p; k7.cpair_blk = h->cpair_blk.p; k7.cpair_row = h->cpair_row.p;
+        k7.Z = h->cZ.p; k7.E[0] = h->cE[0].p; k7.E[1] = h->cE[1].p; k7.scale = h->cscale.p; k7.rc = h->crc.p;
+        k7.Einv = k7.E[0];
+        h->coarse_built = true;
+        h->coarse_from = kCoarseFromIterations;
+        if (const char* e = getenv("SFMBA_PCG_COARSE_FROM")) h->coarse_from = std::max(1, atoi(e));
+        h->coarse_forced = coarse > 0;
+        tr.lap("schur: coarse space");
     }
     if (want_dense) {
         h->dense_n = dense_padded((int)n_red);
@@ -1463,6 +1573,7 @@ void sfmba_default_options(sfmba_options* o) {
     o->rank = 0; o->nranks = 1;
     o->pcg_mode = 0; o->pcg_blocks = 0;
     o->camera_model = SFMBA_CAMERA_PINHOLE;
+    o->pcg_coarse = 0;
 }
 
 int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
@@ -1741,6 +1852,32 @@ int sfmba_get_reduced(sfmba_handle* h, double* rhs, double* precond_inv) {
         need_linearized(h, "sfmba_get_reduced");
         if (rhs) HIP_TRY(hipMemcpy(rhs, h->rhs.p, (size_t)h->n_cam * h->cd * sizeof(double), hipMemcpyDeviceToHost));
         if (precond_inv) HIP_TRY(hipMemcpy(precond_inv, h->Minv.p, (size_t)h->n_cam * h->cd * h->cd * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+int sfmba_precondition(sfmba_handle* h, const double* r, double* z, int32_t* coarse_dim) {
+    return guarded(h, [&] {
+        need_linearized(h, "sfmba_precondition");
+        if (!r || !z) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_precondition: null array");
+        const size_t n = (size_t)h->n_cam * h->cd;
+        // the first kernel of a PCG solve does exactly this for the right-hand side: r -> pr,
+        // M_J^-1 r -> pz, state 0 armed
+        HIP_TRY(hipMemcpyAsync(h->pq.p, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        Dev d = h->dev;
+        d.rhs = h->pq.p;
+        launch_pcg_init(d, 0.1, 1, h->stream);
+        const bool two_level = h->explicit_schur && h->coarse_built;
+        if (two_level) {
+            if (!h->coarse_valid) {
+                h->coarse.Einv = launch_coarse_setup(h->dev, h->coarse, h->stream);
+                h->coarse_valid = true;
+            }
+            launch_coarse_apply(h->dev, h->coarse, 0, h->stream);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(z, h->pz.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (coarse_dim) *coarse_dim = two_level ? h->coarse.n : 0;
     });
 }
 

@@ -133,6 +133,30 @@ struct Dev {
     double* scalars;    // [SLOT_COUNT]
 };
 
+// Coarse space of the two-level PCG preconditioner (sfmba_coarse.hip): seven vectors per cluster
+// of consecutive cameras, E = Z'SZ dense.
+constexpr int kCoarseVecs = 7;
+struct Coarse {
+    int n_cl;                 // clusters
+    int n;                    // 7 n_cl coarse unknowns
+    int n_pad;                // n rounded up to a multiple of 32 (identity on the padding)
+    int n_cpairs;             // cluster pairs (I, J) that share at least one block of S
+    const int* cl_ptr;        // [n_cl+1] camera range of each cluster
+    const int* cam_cl;        // [n_cam] cluster of each camera
+    const int* cpair_i; const int* cpair_j;   // [n_cpairs]
+    int n_cchunks;            // chunks the blocks of the pairs are cut into
+    const int* cpair_cptr;    // [n_cpairs+1] chunk range of each pair
+    const int* cchunk_beg;    // [n_cchunks+1] range of each chunk in cpair_blk / cpair_row
+    double* cpart;            // [n_cchunks][49] chunk partials of E
+    const int* cpair_blk;     // [nnzb] blocks of Sfull grouped by cluster pair
+    const int* cpair_row;     // [nnzb] row camera of each of those blocks
+    double* Z;                // [n_cam][7][ND]
+    double* E[2];             // [n_pad][n_pad] each: assembly, scaling and the sweep alternate between them
+    double* scale;            // [n_pad] D = diag(E)^-1/2
+    double* rc;               // [n_pad] restricted residual (zero on the padding)
+    const double* Einv;       // whichever of E[] holds (D E D)^-1
+};
+
 inline int cam_dim(const Dev& d) { return d.model == MODEL_BAL ? Bal::ND : Pinhole::ND; }
 inline int cam_dim(int model) { return model == MODEL_BAL ? Bal::ND : Pinhole::ND; }
 inline int cam_sums(int model) { return model == MODEL_BAL ? Bal::NV : Pinhole::NV; }      // packed upper + gradient
@@ -184,6 +208,9 @@ void launch_block_reduce(const Dev& d, hipStream_t st);
 void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
+// sfmba_coarse.hip
+const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st);    // returns the buffer holding the inverse
+void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st);  // pz += Z E^-1 Z' pr, r'z partials
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)
 void launch_triangulate(const double* P1, const double* P2, int n, const double2* x1, const double2* x2,
                         double* X, double* err1, double* err2, hipStream_t st);

@@ -20,7 +20,7 @@ EXPORTS = (
     "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
     "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_triangulate", "sfmba_point_errors",
     "sfmba_linearize", "sfmba_get_blocks",
-    "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_solve_step",
+    "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_precondition", "sfmba_solve_step",
     "sfmba_comm_unique_id", "sfmba_comm_init",
     "sfmba_local_group_create", "sfmba_local_group_destroy", "sfmba_comm_init_local",
 )
@@ -50,7 +50,7 @@ class Options(C.Structure):
         ("pcg_max_iter", C.c_int32), ("pcg_batch", C.c_int32), ("linear_solver", C.c_int32), ("schur_mode", C.c_int32),
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
-        ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32), ("camera_model", C.c_int32),
+        ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32), ("camera_model", C.c_int32), ("pcg_coarse", C.c_int32),
     ]
 
 
@@ -74,6 +74,7 @@ class Stats(C.Structure):
         ("ms_bsr", C.c_double), ("n_bsr", C.c_int64),
         ("schur_pairs", C.c_int64), ("schur_blocks", C.c_int64), ("schur_chunks", C.c_int64),
         ("pcg_single_launch", C.c_int64), ("pcg_single_fallbacks", C.c_int64),
+        ("pcg_coarse_solves", C.c_int64), ("pcg_coarse_dim", C.c_int64),
     ]
 
     def as_dict(self):
@@ -116,6 +117,7 @@ def load_library(path=None):
     lib.sfmba_get_blocks.argtypes = [vp, dp, dp, dp, dp]
     lib.sfmba_schur_matvec.argtypes = [vp, dp, dp]
     lib.sfmba_get_reduced.argtypes = [vp, dp, dp]
+    lib.sfmba_precondition.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
     lib.sfmba_solve_step.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
     lib.sfmba_comm_unique_id.argtypes = [vp]
     lib.sfmba_comm_init.argtypes = [vp, vp]
@@ -306,6 +308,14 @@ class Engine:
         rhs = np.empty((self.n_cameras, self.cam_dim)); Minv = np.empty((self.n_cameras, self.cam_dim, self.cam_dim))
         self._check(self._lib.sfmba_get_reduced(self._h, _dp(rhs), _dp(Minv)))
         return rhs, Minv
+
+    def precondition(self, r):
+        """z = M^-1 r of the launch-per-iteration PCG and the coarse dimension (0: block-Jacobi only)."""
+        r = _f64(r).reshape(self.n_cameras, self.cam_dim)
+        z = np.empty_like(r)
+        n = C.c_int32(0)
+        self._check(self._lib.sfmba_precondition(self._h, _dp(r), _dp(z), C.byref(n)))
+        return z, n.value
 
     def solve_step(self):
         dc = np.zeros((self.n_cameras, self.cam_dim)); dp = np.zeros((self.n_points, 3))

@@ -32,7 +32,7 @@ def test_default_options_match_reference_call():
     # bundle_adjustment.py:141: ftol=1e-4, xtol=1e-12; SciPy default gtol=1e-8
     assert (o.ftol, o.xtol, o.gtol) == (1e-4, 1e-12, 1e-8)
     assert o.nranks == 1 and o.rank == 0 and o.device == -1
-    assert o.pcg_mode == 0 and o.pcg_blocks == 0 and o.linear_solver == 0 and o.schur_mode == 0 and o.camera_model == 0
+    assert o.pcg_mode == 0 and o.pcg_blocks == 0 and o.linear_solver == 0 and o.schur_mode == 0 and o.camera_model == 0 and o.pcg_coarse == 0
 
 
 def test_struct_layouts_match_header():

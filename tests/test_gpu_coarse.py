@@ -1,0 +1,124 @@
+"""GPU: the two-level preconditioner of the launch-per-iteration PCG (options.pcg_coarse).
+
+No counterpart in the reference (its LSMR runs unpreconditioned, scipy/optimize/_lsq/trf.py:479);
+the checks are against NumPy algebra on the matrices the engine hands out, and against the
+block-Jacobi solver on the same problems.  Tolerances: 1e-8 relative for the preconditioner
+(two inversions of a 7 n_clusters matrix in fp64), 1e-6 relative for converged costs."""
+import numpy as np
+import pytest
+
+from structure_from_motion_amd import synthetic as syn
+from structure_from_motion_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _rotations(rvec):
+    return syn._rodrigues(np.asarray(rvec, float))
+
+
+def _problem(model, n_cam, n_pts, n_obs, seed):
+    if model == "bal":
+        p = syn.make_bal_problem(n_cam, n_pts, n_obs, seed=seed)
+        p["K"] = None
+    else:
+        p = syn.make_problem(n_cam, n_pts, n_obs, seed=seed)
+    return p
+
+
+def _engine(p, model, **opts):
+    eng = E.Engine(camera_model=model, linear_solver=1, schur_mode=2, **opts)
+    eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
+    return eng
+
+
+def _coarse_basis(eng, model, cluster):
+    """Z (cam_dim n_cam x 7 n_cl) as the header documents it, from the engine's current cameras."""
+    cams, _ = eng.get_params()
+    nc, nd = eng.n_cameras, eng.cam_dim
+    if model == "bal":
+        Q, t = _rotations(cams[:, :3]), cams[:, 3:6]
+    else:
+        Q, t = cams[:, :9].reshape(-1, 3, 3), cams[:, 9:12]
+    V = np.zeros((nc, nd, 7))
+    for a in range(3):
+        u = Q[:, :, a]                      # Q e_a
+        V[:, 3:6, a] = -u
+        V[:, 0:3, 3 + a] = -u
+        V[:, 3:6, 3 + a] = np.cross(u, t)
+    V[:, 3:6, 6] = t
+    n_cl = max(1, nc // cluster)
+    Z = np.zeros((nc * nd, 7 * n_cl))
+    for i in range(n_cl):
+        lo, hi = i * nc // n_cl, (i + 1) * nc // n_cl
+        Z[nd * lo:nd * hi, 7 * i:7 * i + 7] = V[lo:hi].reshape(-1, 7)
+    return Z
+
+
+@pytest.mark.parametrize("model,cluster", [("pinhole", 64), ("pinhole", 48), ("bal", 64)])
+def test_preconditioner_is_block_jacobi_plus_coarse_correction(model, cluster):
+    p = _problem(model, 330, 6000, 40000, seed=5)
+    with _engine(p, model, pcg_coarse=cluster) as eng:
+        eng.linearize(1e-5)
+        nc, nd = eng.n_cameras, eng.cam_dim
+        _, Minv = eng.get_reduced()
+        Z = _coarse_basis(eng, model, cluster)
+        SZ = np.stack([eng.schur_matvec(Z[:, j]).reshape(-1) for j in range(Z.shape[1])], axis=1)
+        Em = Z.T @ SZ
+        assert np.abs(Em - Em.T).max() <= 1e-9 * np.abs(Em).max()
+        rng = np.random.default_rng(0)
+        for _ in range(2):
+            r = rng.normal(size=(nc, nd))
+            z, dim = eng.precondition(r)
+            assert dim == Z.shape[1] == 7 * (nc // cluster)
+            want = np.einsum("nij,nj->ni", Minv, r).reshape(-1) + Z @ np.linalg.solve(Em, Z.T @ r.reshape(-1))
+            assert np.abs(z.reshape(-1) - want).max() <= 1e-8 * np.abs(want).max()
+        # the r'z the solver continues with is symmetric in its arguments
+        a, b = rng.normal(size=(2, nc, nd))
+        za, _ = eng.precondition(a)
+        zb, _ = eng.precondition(b)
+        assert abs(float((b * za).sum() - (a * zb).sum())) <= 1e-9 * abs(float((b * za).sum()))
+
+
+def test_without_coarse_space_the_preconditioner_is_block_jacobi():
+    p = _problem("pinhole", 60, 1500, 9000, seed=6)
+    with _engine(p, "pinhole", pcg_mode=1) as eng:       # below 256 cameras no coarse space is built
+        eng.linearize(1e-4)
+        _, Minv = eng.get_reduced()
+        r = np.random.default_rng(1).normal(size=(60, 6))
+        z, dim = eng.precondition(r)
+    assert dim == 0
+    np.testing.assert_allclose(z, np.einsum("nij,nj->ni", Minv, r), rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("model", ["pinhole", "bal"])
+def test_two_level_solve_same_cost_fewer_iterations(model):
+    p = _problem(model, 400, 30000, 200000, seed=7)
+    out = {}
+    for name, coarse in (("block-jacobi", -1), ("two-level", 64), ("auto", 0)):
+        # (tolerances well below the reference's ftol = 1e-4: the three runs take different inexact
+        # steps and are compared where they end, not where a loose test happens to stop them)
+        with _engine(p, model, pcg_mode=1, pcg_coarse=coarse, ftol=1e-9, gtol=1e-12) as eng:
+            out[name] = eng.solve()
+            again = eng.residuals()
+        assert np.isfinite(again).all()
+        print(name, out[name].final_cost, out[name].iterations, out[name].pcg_iterations)
+    ref = out["block-jacobi"]
+    assert ref.pcg_coarse_solves == 0 and ref.pcg_coarse_dim == 0
+    assert out["two-level"].pcg_coarse_solves == out["two-level"].iterations and out["two-level"].pcg_coarse_dim == 7 * (400 // 64)
+    assert 0 < out["auto"].pcg_coarse_solves < out["auto"].iterations and out["auto"].pcg_coarse_dim == 7 * (400 // 128)
+    for name in ("two-level", "auto"):
+        st = out[name]
+        assert abs(st.final_cost - ref.final_cost) <= 1e-6 * ref.final_cost
+        assert st.pcg_iterations <= ref.pcg_iterations
+    assert out["two-level"].pcg_iterations < 0.6 * ref.pcg_iterations
+
+
+def test_two_level_solve_is_reproducible():
+    p = _problem("pinhole", 300, 8000, 60000, seed=8)
+    costs = []
+    for _ in range(2):
+        with _engine(p, "pinhole", pcg_coarse=64) as eng:
+            st = eng.solve()
+            costs.append((st.final_cost, st.pcg_iterations, st.iterations))
+    assert costs[0] == costs[1]

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
            "pcg-explicit": dict(linear_solver=1, schur_mode=2, pcg_mode=2),
            "pcg-explicit-stepwise": dict(linear_solver=1, schur_mode=2, pcg_mode=1),
+           "pcg-explicit-coarse": dict(linear_solver=1, schur_mode=2, pcg_coarse=48),
            "dense": dict(linear_solver=2)}
 
 
@@ -66,6 +67,22 @@ def test_sharded_solve_matches_single_handle(solver, nranks):
         assert np.abs(pts - ref_pts).max() <= 1e-7
         assert abs(o.cost(g, poses, pts) - st["final_cost"]) <= 1e-9 * st["final_cost"]
     # every rank returns the same full result
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_sharded_two_level_solve():
+    # several clusters; the coarse matrix is built from the all-reduced blocks on every rank
+    p = syn.make_problem(300, 8000, 60000, seed=8)
+    opts = dict(linear_solver=1, schur_mode=2, pcg_coarse=64)
+    with E.Engine(**opts) as eng:
+        eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
+                        p["points_2d"], p["K"])
+        ref = eng.solve()
+    assert ref.pcg_coarse_dim == 28 and ref.pcg_coarse_solves == ref.iterations
+    out = solve_sharded(p, 2, **opts)
+    for st, _, _ in out:
+        assert st["iterations"] == ref.iterations and st["pcg_coarse_solves"] == ref.pcg_coarse_solves
+        assert abs(st["final_cost"] - ref.final_cost) <= 1e-9 * ref.final_cost
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
