@@ -82,4 +82,13 @@ with Engine(max_iterations=4) as eng:
                 pdir = z + (rzn / rz) * pdir; rz = rzn
             return maxit, x
         it, x = pcg2(bb)
+        if nv == 7:
+            # the coarse solve as the initial guess only, block-Jacobi PCG on the rest, stopping at
+            # the same r'M^-1 r as the plain solve
+            x00 = Z @ (Einv @ (Z.T @ bb))
+            r00 = bb - S(x00)
+            rz_plain = bb @ M(bb)
+            rz_start = r00 @ M(r00)
+            itg, xg = pcg(r00, rtol=0.1 * np.sqrt(rz_plain / rz_start))
+            print(f"   coarse initial guess, then block-Jacobi PCG: {itg} iterations, start r'z ratio {rz_start / rz_plain:.3g}, residual/model {quality(x00 + xg)}", flush=True)
         print(f"two-level, clusters of {k} cameras, vectors {cols} (coarse dimension {Z.shape[1]}): {it} iterations, residual/model {quality(x)} (setup {time.time()-t0:.1f}s)", flush=True)

@@ -146,59 +146,80 @@ __global__ __launch_bounds__(kBlock) void k_coarse_gj(const double* __restrict__
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int i = ty + 8 * m;
-        P[i][tx] = src[(size_t)(kTile * p + i) * n_pad + kTile * p + tx];
         if (!row_p) A[i][tx] = src[(size_t)(kTile * bi + i) * n_pad + kTile * p + tx];
         if (!col_p) B[i][tx] = src[(size_t)(kTile * p + i) * n_pad + kTile * bj + tx];
     }
-    for (int kk = 0; kk < kTile; ++kk) {
-        __syncthreads();
-        const double pv = P[kk][kk];
-        const double piv = (pv > 1e-300 && pv < 1e300) ? 1.0 / pv : 0.0;
-        const double rowk = P[kk][tx];
-        double colv[4], old[4];
+    // the pivot block: every thread keeps its four entries (rows ty + 8 m, column tx) in registers;
+    // a step publishes the pivot row and column through LDS buffers that alternate with the
+    // step's parity, so one barrier per step is enough
+    __shared__ double rowbuf[2][kTile], colbuf[2][kTile];
+    double pv[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { colv[m] = P[ty + 8 * m][kk]; old[m] = P[ty + 8 * m][tx]; }
+    for (int m = 0; m < 4; ++m) pv[m] = src[(size_t)(kTile * p + ty + 8 * m) * n_pad + kTile * p + tx];
+#pragma unroll
+    for (int kk = 0; kk < kTile; ++kk) {
+        const int par = kk & 1;
+        if (ty == (kk & 7)) rowbuf[par][tx] = pv[kk >> 3];
+        if (tx == kk) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) colbuf[par][ty + 8 * m] = pv[m];
+        }
         __syncthreads();
+        const double pd = rowbuf[par][kk];
+        const double piv = (pd > 1e-300 && pd < 1e300) ? 1.0 / pd : 0.0;
+        const double rowk = rowbuf[par][tx];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int i = ty + 8 * m;
+            const double colv = colbuf[par][i];
             double v;
             if (i == kk) v = tx == kk ? piv : rowk * piv;
-            else v = tx == kk ? -colv[m] * piv : old[m] - colv[m] * piv * rowk;
-            P[i][tx] = v;
+            else v = tx == kk ? -colv * piv : pv[m] - colv * piv * rowk;
+            pv[m] = v;
         }
     }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) P[ty + 8 * m][tx] = pv[m];
     __syncthreads();
     double out[4];
     if (row_p && col_p) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) out[m] = P[ty + 8 * m][tx];
     } else if (row_p) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            double s = 0.0;
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 8
-            for (int q = 0; q < kTile; ++q) s += P[ty + 8 * m][q] * B[q][tx];
-            out[m] = s;
+        for (int q = 0; q < kTile; ++q) {
+            const double b = B[q][tx];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) s[m] += P[ty + 8 * m][q] * b;
         }
-    } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            double s = 0.0;
+        for (int m = 0; m < 4; ++m) out[m] = s[m];
+    } else {
+        {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 8
-            for (int q = 0; q < kTile; ++q) s += A[ty + 8 * m][q] * P[q][tx];
-            T[ty + 8 * m][tx] = s;
-            out[m] = -s;
+            for (int q = 0; q < kTile; ++q) {
+                const double b = P[q][tx];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) s[m] += A[ty + 8 * m][q] * b;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { T[ty + 8 * m][tx] = s[m]; out[m] = -s[m]; }
         }
         if (!col_p) {
             __syncthreads();
+            double s[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                double s = src[(size_t)(kTile * bi + ty + 8 * m) * n_pad + kTile * bj + tx];
+            for (int m = 0; m < 4; ++m) s[m] = src[(size_t)(kTile * bi + ty + 8 * m) * n_pad + kTile * bj + tx];
 #pragma unroll 8
-                for (int q = 0; q < kTile; ++q) s -= T[ty + 8 * m][q] * B[q][tx];
-                out[m] = s;
+            for (int q = 0; q < kTile; ++q) {
+                const double b = B[q][tx];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) s[m] -= T[ty + 8 * m][q] * b;
             }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) out[m] = s[m];
         }
     }
 #pragma unroll
@@ -243,18 +264,34 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
     __shared__ double red[16];
     __shared__ double y[2 * kVecs];
     if (d.pcg[state].done) return;
-    const int c0 = blockIdx.x * kCams;
+    // neighbouring workgroups need the same rows of Einv: keep them on one die's L2
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int c0 = blk * kCams;
     const int c1 = min(c0 + kCams, d.n_cam) - 1;
     const int I0 = k.cam_cl[c0];
     const int nrows = min(kVecs * (k.cam_cl[c1] - I0 + 1), 2 * kVecs);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int row = w; row < nrows; row += kBlock / 64) {
-        const int g = kVecs * I0 + row;
-        const double* __restrict__ e = k.Einv + (size_t)g * k.n_pad;
-        double s = 0.0;
-        for (int j = lane; j < k.n_pad; j += 64) s += e[j] * k.rc[j];
-        s = wave_sum(s);
-        if (lane == 0) y[row] = k.scale[g] * s;
+    {
+        // wavefront w takes rows w, w + 4, w + 8, w + 12: their loads are issued together
+        constexpr int kRowsPerWave = (2 * kVecs + kBlock / 64 - 1) / (kBlock / 64);
+        const double* __restrict__ e0 = k.Einv + (size_t)(kVecs * I0) * k.n_pad;
+        double s[kRowsPerWave];
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; ++q) s[q] = 0.0;
+        for (int j = lane; j < k.n_pad; j += 64) {
+            const double rj = k.rc[j];
+#pragma unroll
+            for (int q = 0; q < kRowsPerWave; ++q) {
+                const int row = w + (kBlock / 64) * q;
+                if (row < nrows) s[q] += e0[(size_t)row * k.n_pad + j] * rj;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; ++q) {
+            const int row = w + (kBlock / 64) * q;
+            const double t = wave_sum(s[q]);
+            if (row < nrows && lane == 0) y[row] = k.scale[kVecs * I0 + row] * t;
+        }
     }
     __syncthreads();
     const int local = threadIdx.x / ND, kk = threadIdx.x - ND * local;
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
         dot = d.pr[o] * z;
     }
     const double s = block_sum(dot, red);
-    if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
+    if (threadIdx.x == 0) d.dot_part[d.dot_off + blk] = s;
 }
 
 // ---- launch wrappers --------------------------------------------------------------------
