@@ -123,3 +123,20 @@ def test_bal_full_solve_converges_to_the_noise_floor_on_both_schur_paths(venice_
         assert cams.shape == (venice_bal["n_cameras"], 9) and pts.shape == (venice_bal["n_points"], 3)
         costs.append(st.final_cost)
     assert abs(costs[0] - costs[1]) <= 1e-6 * costs[0]
+
+
+def test_two_level_preconditioner_beyond_the_single_launch_solver():
+    # 2 736 cameras: more than the single-launch PCG takes, so the default policy is the
+    # launch-per-iteration solver, which switches its coarse space on once the solves get long
+    p = syn.make_shape("final", seed=0, scale=0.2)
+    out = {}
+    for name, coarse in (("block-jacobi", -1), ("default", 0)):
+        with _engine(p, pcg_coarse=coarse) as eng:
+            out[name] = eng.solve()
+    ref, st = out["block-jacobi"], out["default"]
+    assert ref.pcg_single_launch == 0 and st.pcg_single_launch == 0
+    assert ref.pcg_coarse_solves == 0 and 0 < st.pcg_coarse_solves < st.iterations
+    assert st.pcg_coarse_dim == 7 * (p["n_cameras"] // 128)
+    assert st.status == ref.status and st.iterations == ref.iterations
+    assert abs(st.final_cost - ref.final_cost) <= 1e-6 * ref.final_cost
+    assert st.pcg_iterations < 0.5 * ref.pcg_iterations
