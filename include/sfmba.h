@@ -87,8 +87,9 @@ typedef struct sfmba_options {
      * and whatever pcg_mode 0 resolves to when the single-launch solver does not apply): next to
      * the block-Jacobi blocks, a coarse space of seven vectors (translation, rotation, scale of
      * the world) per cluster of consecutive cameras, M^-1 = M_J^-1 + Z (Z'SZ)^-1 Z'.
-     *   0 = choose: built for 256 cameras and more, clusters of 128; a solve uses it once an
-     *       earlier solve of the same sfmba_solve took 24 iterations or more;
+     *   0 = choose: built for 256 cameras and more, clusters of k = n_cameras / 100 cameras kept
+     *       within 48..128; a solve uses it once an earlier solve of the same sfmba_solve took
+     *       24 iterations or more;
      *  -1 = never;
      *   k > 0 = clusters of k cameras (at least 48; raised where 7 n_cameras / k would exceed 4096),
      *       used from the first solve on; selects pcg_mode 1.

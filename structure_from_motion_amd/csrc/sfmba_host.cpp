@@ -1258,7 +1258,10 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     // and large enough that the dense coarse matrix stays below 4096 x 4096.
     h->coarse_built = false; h->coarse_forced = false; h->coarse_on = false; h->coarse_valid = false;
     if (coarse >= 0 && !want_dense && !h->fused_pcg && (coarse > 0 || n_cam >= 256)) {
-        int k = coarse > 0 ? std::max(coarse, 48) : 128;
+        // (left to choose: about a hundred clusters, of 48 to 128 cameras: the set-up grows with
+        // the cube of their number, the iteration count with their size; measured best at the
+        // Venice shape with 48 and at the Final shape with 128)
+        int k = coarse > 0 ? std::max(coarse, 48) : std::min(128, std::max(48, n_cam / 100));
         k = std::max(k, (int)((7LL * n_cam + 4095) / 4096));
         const int n_cl = std::max(1, n_cam / k);
         std::vector<int> cl_ptr((size_t)n_cl + 1), cam_cl((size_t)n_cam);
@@ -1316,8 +1319,11 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         k7.Einv = k7.E[0];
         h->coarse_built = true;
         h->coarse_from = kCoarseFromIterations;
-        if (const char* e = getenv("SFMBA_PCG_COARSE_FROM")) h->coarse_from = std::max(1, atoi(e));
         h->coarse_forced = coarse > 0;
+        if (const char* e = getenv("SFMBA_PCG_COARSE_FROM")) {     // tuning: the switch-on rule with any cluster size
+            h->coarse_from = std::max(1, atoi(e));
+            h->coarse_forced = false;
+        }
         tr.lap("schur: coarse space");
     }
     if (want_dense) {

@@ -136,7 +136,7 @@ def test_two_level_preconditioner_beyond_the_single_launch_solver():
     ref, st = out["block-jacobi"], out["default"]
     assert ref.pcg_single_launch == 0 and st.pcg_single_launch == 0
     assert ref.pcg_coarse_solves == 0 and 0 < st.pcg_coarse_solves < st.iterations
-    assert st.pcg_coarse_dim == 7 * (p["n_cameras"] // 128)
+    assert st.pcg_coarse_dim == 7 * (p["n_cameras"] // 48)
     assert st.status == ref.status and st.iterations == ref.iterations
     assert abs(st.final_cost - ref.final_cost) <= 1e-6 * ref.final_cost
     assert st.pcg_iterations < 0.5 * ref.pcg_iterations
