@@ -122,3 +122,16 @@ def test_two_level_solve_is_reproducible():
             st = eng.solve()
             costs.append((st.final_cost, st.pcg_iterations, st.iterations))
     assert costs[0] == costs[1]
+
+
+def test_a_two_level_solve_that_does_not_converge_is_redone_without_the_coarse_space():
+    # an iteration cap the later solves cannot meet: the first of them is redone with the
+    # block-Jacobi blocks alone and the coarse space stays off for the rest of the run
+    p = _problem("pinhole", 300, 8000, 60000, seed=8)
+    with _engine(p, "pinhole", pcg_coarse=64, pcg_max_iter=3) as eng:
+        capped = eng.solve()
+    with _engine(p, "pinhole", pcg_coarse=-1, pcg_mode=1, pcg_max_iter=3) as eng:
+        plain = eng.solve()
+    assert 0 < capped.pcg_coarse_solves < capped.iterations
+    assert np.isfinite(capped.final_cost) and capped.final_cost < 0.01 * capped.initial_cost
+    assert capped.final_cost <= plain.final_cost * 1.05
