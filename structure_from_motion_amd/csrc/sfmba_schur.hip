@@ -24,13 +24,10 @@ namespace sfmba {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <class M>
-__global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
-    constexpr int ND = M::ND, NN = ND * ND;
-    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 20];
-    const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
-    if (q >= d.n_pchunks) return;
+// Rows [I0, I1) of the block sums of pair chunk q.
+template <class M, int I0, int I1>
+__device__ __forceinline__ void schur_pairs_rows(const Dev& d, int q, int lane, double* lds) {
+    constexpr int ND = M::ND, NN = (I1 - I0) * ND;
     const int blk = __builtin_amdgcn_readfirstlane(d.pchunk_blk[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q]);
     const int k1 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q + 1]);
@@ -74,22 +71,49 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
         // column 4 no u entry: products with those zeros are left out)
         constexpr bool kZ = M::kDiagonalPixelMap;
 #pragma unroll
-        for (int i = 0; i < ND; ++i) {
+        for (int i = I0; i < I1; ++i) {
             const double l0 = kZ && i == 3 ? jca[i] * m00 : kZ && i == 4 ? jca[ND + i] * m10 : jca[i] * m00 + jca[ND + i] * m10;
             const double l1 = kZ && i == 3 ? jca[i] * m01 : kZ && i == 4 ? jca[ND + i] * m11 : jca[i] * m01 + jca[ND + i] * m11;
 #pragma unroll
             for (int j = 0; j < ND; ++j)
-                acc[ND * i + j] += kZ && j == 3 ? l0 * jcb[j] : kZ && j == 4 ? l1 * jcb[ND + j] : l0 * jcb[j] + l1 * jcb[ND + j];
+                acc[ND * (i - I0) + j] += kZ && j == 3 ? l0 * jcb[j] : kZ && j == 4 ? l1 * jcb[ND + j] : l0 * jcb[j] + l1 * jcb[ND + j];
         }
     }
     constexpr int kPasses = (NN + 17) / 18;
     double tot[kPasses];
-    wave_sum_lds<NN, 18>(acc, lds + (threadIdx.x >> 6) * (64 * 20), lane, tot);
+    wave_sum_lds<NN, 18>(acc, lds, lane, tot);
     if (lane < 18) {
-        double* o = d.pair_part + NN * (size_t)q;
+        double* o = d.pair_part + ND * ND * (size_t)q + ND * I0;
 #pragma unroll
         for (int p = 0; p < kPasses; ++p)
             if (18 * p + lane < NN) o[18 * p + lane] = tot[p];
+    }
+}
+
+// kSplit = 2: blockIdx.y picks the upper or lower half of the block's rows, so that a lane carries
+// half of the running sums (the 81 sums of a 9 x 9 block leave one wavefront per SIMD, and the
+// kernel waits on its gathers) at the price of forming the pair's 2 x 2 core twice: two wavefronts
+// per SIMD, 570 -> 530 us per launch at the Venice shape.  (Three thirds still need 236 registers
+// and ran at 750 us; a 168-register budget spills 69 of them.)
+template <class M, int kSplit>
+__global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
+    constexpr int ND = M::ND;
+    __shared__ __attribute__((aligned(16))) double lds_all[(kBlock / 64) * 64 * 20];
+    double* lds = lds_all + (threadIdx.x >> 6) * (64 * 20);
+    const int lane = threadIdx.x & 63;
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_pchunks) return;
+    if constexpr (kSplit == 1) {
+        schur_pairs_rows<M, 0, ND>(d, q, lane, lds);
+    } else if constexpr (kSplit == 2) {
+        constexpr int kHalf = (ND + 1) / 2;
+        if (blockIdx.y == 0) schur_pairs_rows<M, 0, kHalf>(d, q, lane, lds);
+        else schur_pairs_rows<M, kHalf, ND>(d, q, lane, lds);
+    } else {
+        constexpr int kThird = ND / 3;
+        if (blockIdx.y == 0) schur_pairs_rows<M, 0, kThird>(d, q, lane, lds);
+        else if (blockIdx.y == 1) schur_pairs_rows<M, kThird, 2 * kThird>(d, q, lane, lds);
+        else schur_pairs_rows<M, 2 * kThird, ND>(d, q, lane, lds);
     }
 }
 
@@ -282,8 +306,8 @@ int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kBlock / cam_dim(d)); }
 void launch_schur_pairs(const Dev& d, hipStream_t st) {
     if (d.n_pchunks == 0) return;
     const dim3 grid(cdiv(d.n_pchunks, kBlock / 64));
-    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_schur_pairs<Bal>), grid, dim3(kBlock), 0, st, d);
-    else hipLaunchKernelGGL((k_schur_pairs<Pinhole>), grid, dim3(kBlock), 0, st, d);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_schur_pairs<Bal, 2>), dim3(grid.x, 2), dim3(kBlock), 0, st, d);
+    else hipLaunchKernelGGL((k_schur_pairs<Pinhole, 1>), grid, dim3(kBlock), 0, st, d);
 }
 void launch_block_reduce(const Dev& d, hipStream_t st) {
     const int nn = cam_dim(d) * cam_dim(d);
