@@ -93,7 +93,10 @@ typedef struct sfmba_options {
      *  -1 = never;
      *   k > 0 = clusters of k cameras (at least 48; raised where 7 n_cameras / k would exceed 4096),
      *       used from the first solve on; selects pcg_mode 1.
-     * n_cl = max(1, n_cameras / k) clusters, cluster i = cameras [i n_cameras / n_cl, (i+1) n_cameras / n_cl). */
+     * n_cl = n_cameras / k clusters, cluster i = cameras [i n_cameras / n_cl, (i+1) n_cameras / n_cl);
+     * with fewer than two clusters no coarse space is built (one cluster would hold the gauge
+     * directions of the whole problem, on which S vanishes up to the damping).  Cameras without
+     * observations take no part in it and do not move. */
     int32_t pcg_coarse;
 } sfmba_options;
 

@@ -15,7 +15,8 @@
 //     world translation e_a :  dw = 0,          dt = -Q e_a
 //     world rotation    e_k :  dw = -Q e_k,     dt = (Q e_k) x t
 //     world scaling         :  dw = 0,          dt = t
-// (intrinsic entries of the tangent, where the camera model has any, are zero).  E is small
+// (intrinsic entries of the tangent, where the camera model has any, are zero, and so is the whole
+// of Z for a camera nobody observes).  E is small
 // (7 x clusters) and dense; it is assembled from the block-CSR matrix once per damping, scaled to
 // unit diagonal and inverted in place by a blocked Gauss-Jordan sweep, one launch per 32 columns.
 // Each PCG iteration then costs two more small launches: the restriction Z' r and the
@@ -51,9 +52,15 @@ __global__ __launch_bounds__(kBlock) void k_coarse_basis(Dev d, Coarse k) {
         z[(3 + a) * ND + 5] = u0 * cam.t[1] - u1 * cam.t[0];
     }
     z[6 * ND + 3] = cam.t[0]; z[6 * ND + 4] = cam.t[1]; z[6 * ND + 5] = cam.t[2];
+    // a camera without observations (on any rank: U is the all-ranks sum) has a zero right-hand
+    // side and must not move: it takes no part in the coarse space
+    const double* __restrict__ U = d.UG + M::NV * (size_t)c;
+    bool seen = false;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) seen = seen || U[upidx(ND, i, i)] != 0.0;
     double* out = k.Z + kVecs * ND * (size_t)c;
 #pragma unroll
-    for (int i = 0; i < kVecs * ND; ++i) out[i] = z[i];
+    for (int i = 0; i < kVecs * ND; ++i) out[i] = seen ? z[i] : 0.0;
 }
 
 // E(I, J) = sum over the blocks (r, c) of S with r in cluster I, c in cluster J of Z_r' S_rc Z_c.

@@ -616,9 +616,10 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
     }
     if (two_level) {
         h->coarse_solves++;
-        if (!(st.rz <= st.tol2 * st.rz0)) {
-            // did not converge (or produced a NaN): the coarse matrix was too ill-conditioned to
-            // invert; this solve and the rest of the run use the block-Jacobi blocks alone
+        if (!(st.rz0 >= 0.0 && st.rz >= 0.0 && st.rz <= st.tol2 * st.rz0)) {
+            // did not converge, produced a NaN, or r'M^-1 r came out negative (a preconditioner that
+            // is not positive definite): the coarse matrix was too ill-conditioned to invert; this
+            // solve and the rest of the run use the block-Jacobi blocks alone
             h->coarse_on = false;
             h->coarse_failed = true;
             return phase_pcg(h, lambda, allow_fused);
@@ -1257,13 +1258,17 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     // than the cameras one workgroup of the vector kernels handles (k_coarse_prolong relies on it)
     // and large enough that the dense coarse matrix stays below 4096 x 4096.
     h->coarse_built = false; h->coarse_forced = false; h->coarse_on = false; h->coarse_valid = false;
-    if (coarse >= 0 && !want_dense && !h->fused_pcg && (coarse > 0 || n_cam >= 256)) {
-        // (left to choose: about a hundred clusters, of 48 to 128 cameras: the set-up grows with
-        // the cube of their number, the iteration count with their size; measured best at the
-        // Venice shape with 48 and at the Final shape with 128)
-        int k = coarse > 0 ? std::max(coarse, 48) : std::min(128, std::max(48, n_cam / 100));
-        k = std::max(k, (int)((7LL * n_cam + 4095) / 4096));
-        const int n_cl = std::max(1, n_cam / k);
+    // (left to choose: about a hundred clusters, of 48 to 128 cameras: the set-up grows with the
+    // cube of their number, the iteration count with their size; measured best at the Venice shape
+    // with 48 and at the Final shape with 128)
+    int coarse_k = coarse > 0 ? std::max(coarse, 48) : std::min(128, std::max(48, n_cam / 100));
+    coarse_k = std::max(coarse_k, (int)((7LL * n_cam + 4095) / 4096));
+    // (a single cluster would span the gauge directions of the whole problem and nothing else: S
+    // vanishes on them up to the damping, the coarse matrix is rounding noise and the iteration
+    // gains nothing; at least two clusters are required)
+    if (coarse >= 0 && !want_dense && !h->fused_pcg && (coarse > 0 || n_cam >= 256) && n_cam / coarse_k >= 2) {
+        const int k = coarse_k;
+        const int n_cl = n_cam / k;
         std::vector<int> cl_ptr((size_t)n_cl + 1), cam_cl((size_t)n_cam);
         for (int i = 0; i <= n_cl; ++i) cl_ptr[i] = (int)((int64_t)i * n_cam / n_cl);
         for (int i = 0; i < n_cl; ++i)

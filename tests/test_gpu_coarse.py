@@ -135,3 +135,31 @@ def test_a_two_level_solve_that_does_not_converge_is_redone_without_the_coarse_s
     assert 0 < capped.pcg_coarse_solves < capped.iterations
     assert np.isfinite(capped.final_cost) and capped.final_cost < 0.01 * capped.initial_cost
     assert capped.final_cost <= plain.final_cost * 1.05
+
+
+@pytest.mark.parametrize("model", ["pinhole", "bal"])
+def test_unobserved_camera_stays_where_it_is(model):
+    # the reference's step for a camera nobody observes is exactly zero (its Jacobian columns are
+    # empty); the coarse vectors of its cluster must not drag it along
+    p = _problem(model, 130, 3000, 20000, seed=9)
+    keep = p["camera_indices"] != 70
+    q = dict(p, camera_indices=p["camera_indices"][keep], point_indices=p["point_indices"][keep], points_2d=p["points_2d"][keep])
+    with _engine(q, model, pcg_coarse=48) as eng:
+        st = eng.solve()
+        cams, _ = eng.get_params()
+    assert st.pcg_coarse_dim == 14 and st.pcg_coarse_solves == st.iterations
+    assert st.final_cost < 0.05 * st.initial_cost
+    if model == "bal":
+        assert np.array_equal(cams[70, 3:], p["camera_params"][70, 3:])      # (the rotation vector goes through a matrix)
+        assert np.abs(cams[70, :3] - p["camera_params"][70, :3]).max() <= 1e-12
+    else:
+        assert np.array_equal(cams[70, 9:], p["camera_params"][70, 9:])
+        assert np.abs(cams[70, :9] - p["camera_params"][70, :9]).max() <= 1e-12
+    assert np.abs(cams[69] - p["camera_params"][69]).max() > 1e-6            # its neighbours do move
+
+
+def test_a_single_cluster_is_not_built():
+    p = _problem("pinhole", 80, 2000, 12000, seed=10)
+    with _engine(p, "pinhole", pcg_coarse=48) as eng:      # 80 // 48 = 1 cluster: the global gauge only
+        st = eng.solve()
+    assert st.pcg_coarse_dim == 0 and st.pcg_coarse_solves == 0

@@ -18,7 +18,6 @@ pytestmark = pytest.mark.gpu
 SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
            "pcg-explicit": dict(linear_solver=1, schur_mode=2, pcg_mode=2),
            "pcg-explicit-stepwise": dict(linear_solver=1, schur_mode=2, pcg_mode=1),
-           "pcg-explicit-coarse": dict(linear_solver=1, schur_mode=2, pcg_coarse=48),
            "dense": dict(linear_solver=2)}
 
 
