@@ -206,6 +206,8 @@ struct sfmba_handle {
     double lin_lambda = 0.0;
     double damped_lambda = -1.0;   // damping for which Vinv and s0 are current
     bool have_v = false;           // V_p and g_p of the current linearisation are in memory
+    bool fuse_cm = false;          // explicit matrix: one camera-major pass instead of two when the damping is known
+    double cm_lambda = -1.0;       // damping for which the one-pass camera sums (UG, T) are current; < 0: two passes
 
     // global shape and this partition
     int64_t n_cam = 0, n_pts_all = 0, n_obs_all = 0;
@@ -426,8 +428,15 @@ void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false) {
     launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only, /*keep_v=*/false);
     h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
     h->have_v = !grad_only && !(lambda > 0.0);
-    launch_lin_cm(h->dev, h->stream, grad_only);
-    launch_chunk_reduce(h->dev, h->cv, h->UG.p, h->stream);
+    if (h->fuse_cm && h->explicit_schur && lambda > 0.0 && !grad_only) {
+        // the points are damped already: U_c - T_c in one camera-major pass (phase_damp finds it done)
+        launch_lin_sdiag_cm(h->dev, h->Bsum.p + (size_t)h->n_ublk * h->cd * h->cd, h->stream);
+        h->cm_lambda = lambda;
+    } else {
+        launch_lin_cm(h->dev, h->stream, grad_only);
+        launch_chunk_reduce(h->dev, h->cv, h->UG.p, h->stream);
+        h->cm_lambda = -1.0;
+    }
     if (h->has_comm()) {
         // one collective for the camera blocks and the gradient maximum over the points: the
         // maximum travels as one slot per rank behind the blocks (a sum all-reduce of slots of
@@ -461,10 +470,17 @@ void phase_damp(H* h, double lambda) {
             Scope t(h, F_DAMP);
             damp_points(h, lambda);
         }
-        {
+        if (h->cm_lambda < 0.0) {
             Scope t(h, F_DAMP);
             launch_sdiag_cm(h->dev, h->stream);
             launch_chunk_reduce(h->dev, h->cv, tpart, h->stream);
+        } else if (h->cm_lambda != lambda) {
+            // another damping of a linearisation whose camera sums were formed in one pass (a
+            // rejected step): the pass again, with the new Vinv and s0
+            Scope t(h, F_DAMP);
+            launch_lin_sdiag_cm(h->dev, tpart, h->stream);
+            h->cm_lambda = lambda;
+            if (h->has_comm()) allreduce(h, h->UG.p, (size_t)h->n_cam * h->cv);
         }
         {
             Scope t(h, F_SCHUR);
@@ -1213,6 +1229,11 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     tr.lap("schur: upload");
     h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
     h->explicit_schur = true;
+    // one camera-major pass per linearisation instead of two (k_lin_sdiag_cm): measured for the
+    // 6-number camera; the 9-number camera would carry 72 running sums per lane
+    h->fuse_cm = h->model == MODEL_PINHOLE;
+    if (const char* e = getenv("SFMBA_FUSE_CM")) h->fuse_cm = atoi(e) != 0;
+    h->cm_lambda = -1.0;
     // single-launch PCG: one workgroup per compute unit at most, every workgroup co-resident
     int pcg_mode = h->opt.pcg_mode;
     if (const char* e = getenv("SFMBA_PCG_MODE")) pcg_mode = atoi(e);
@@ -1513,7 +1534,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->V.zero(st); h->gp.zero(st);      // points without observations are never written
     h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
     const size_t cd = (size_t)h->cd, cv = (size_t)h->cv;
-    h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * cv);
+    h->chunk_part.alloc((size_t)std::max(h->n_chunks, 1) * std::max<int>((int)cv, lin_sdiag_values(h->model)));
     h->UG.alloc((size_t)n_cam * cv + (size_t)std::max(1, h->opt.nranks)); h->T.alloc((size_t)n_cam * cv);
     h->UG.zero(h->stream);
     h->Minv.alloc((size_t)n_cam * cd * cd); h->rhs.alloc((size_t)n_cam * cd);

@@ -170,6 +170,10 @@ void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStr
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only = false, bool keep_v = true);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
 void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only = false);               // chunk partials (NU + ND values)
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
+// launch_lin_cm + launch_sdiag_cm + both reductions in one pass (damping known, explicit matrix):
+// UG and tpart receive what k_finish_diag needs of them; chunk rows of lin_sdiag_values() sums
+int lin_sdiag_values(int model);
+void launch_lin_sdiag_cm(const Dev& d, double* tpart, hipStream_t st);
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st);
 void launch_sdiag_cm(const Dev& d, hipStream_t st);             // chunk partials (NU + ND values)
 void launch_precond(const Dev& d, double lambda, hipStream_t st);

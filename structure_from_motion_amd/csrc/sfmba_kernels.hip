@@ -360,6 +360,115 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
     chunk_store<NV>(d, q, acc, lds, lane);
 }
 
+// Both camera-major passes in one, for a linearisation whose damping is already known (the points
+// were damped by k_lin_pm in the same pass, so Vinv and s0 are current) and whose reduced matrix is
+// built explicitly.  What the diagonal block needs of U_c and T_c is their difference, formed per
+// observation as Jc' (I - Jp Vinv Jp') Jc, plus the diagonal of U_c for the damping term; the
+// chunk row holds NU + 3 ND sums:
+//     [0, NU)            upper triangle: (U - T)_ij off the diagonal, U_ii on it
+//     [NU, NU + ND)      g_c
+//     [NU + ND, +ND)     T_ii
+//     [NU + 2 ND, +ND)   sum W s0 (the point part of the reduced right-hand side)
+// (198 registers, two wavefronts per SIMD; held to 168 and three wavefronts it runs no faster: the
+// gathers of X, Vinv and s0 bound it, 150 us against 80 + 88 us for the two passes it replaces.)
+// k_chunk_reduce_fused spreads them over UG and the T array so that every consumer of the two
+// separate passes (k_finish_diag: S_cc = U* - T - B) finds what it expects: UG = (upper, g_c) as
+// above, T = (T_ii on the diagonal, zero off it | sum W s0).
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_lin_sdiag_cm(Dev d) {
+    constexpr int ND = M::ND, NU = M::NU, NF = NU + 3 * ND;
+    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
+    const int lane = threadIdx.x & 63;
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= d.n_chunks) return;
+    const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
+    const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
+    const int k1 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q + 1]);
+    const typename M::Cam cam = M::load(d.cams, c);
+    double acc[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i] = 0.0;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        const int p = d.cm_pt[k];
+        const double4 X = d.X[p];
+        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
+        const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        const double4 s0 = d.s0[p];
+        const double2 uv = d.cm_uv[k];
+        const Seed s = M::seed(cam, X.x, X.y, X.z);
+        const typename M::Obs ob = M::obs(s, cam, d.K);
+        double ru, rv;
+        M::residual(ob, uv.x, uv.y, ru, rv);
+        d.cm_sx[k] = s.x; d.cm_sy[k] = s.y; d.cm_siz[k] = s.iz;
+        double jc[2 * ND], a[3], b[3];
+        M::jac_cam(ob, jc);
+        M::jac_pt(ob, cam.q, a, b);
+        const double ta0 = v01.x * a[0] + v01.y * a[1] + v23.x * a[2];
+        const double ta1 = v01.y * a[0] + v23.y * a[1] + v45.x * a[2];
+        const double ta2 = v23.x * a[0] + v45.x * a[1] + v45.y * a[2];
+        const double tb0 = v01.x * b[0] + v01.y * b[1] + v23.x * b[2];
+        const double tb1 = v01.y * b[0] + v23.y * b[1] + v45.x * b[2];
+        const double tb2 = v23.x * b[0] + v45.x * b[1] + v45.y * b[2];
+        const double m00 = a[0] * ta0 + a[1] * ta1 + a[2] * ta2;
+        const double m01 = a[0] * tb0 + a[1] * tb1 + a[2] * tb2;
+        const double m11 = b[0] * tb0 + b[1] * tb1 + b[2] * tb2;
+        const double p00 = 1.0 - m00, p01 = -m01, p11 = 1.0 - m11;
+        // (pinhole model: jc[4] and jc[ND + 3] are zero, products with them are left out)
+        constexpr bool kZ = M::kDiagonalPixelMap;
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const double l0 = kZ && i == 3 ? jc[i] * p00 : kZ && i == 4 ? jc[ND + i] * p01 : jc[i] * p00 + jc[ND + i] * p01;
+            const double l1 = kZ && i == 3 ? jc[i] * p01 : kZ && i == 4 ? jc[ND + i] * p11 : jc[i] * p01 + jc[ND + i] * p11;
+            const double uii = kZ && i == 3 ? jc[i] * jc[i] : kZ && i == 4 ? jc[ND + i] * jc[ND + i] : jc[i] * jc[i] + jc[ND + i] * jc[ND + i];
+            const double tii = kZ && i == 3 ? jc[i] * jc[i] * m00 : kZ && i == 4 ? jc[ND + i] * jc[ND + i] * m11
+                               : jc[i] * (jc[i] * m00 + jc[ND + i] * m01) + jc[ND + i] * (jc[i] * m01 + jc[ND + i] * m11);
+            acc[n++] += uii;
+            acc[NU + ND + i] += tii;
+#pragma unroll
+            for (int j = i + 1; j < ND; ++j)
+                acc[n++] += kZ && j == 3 ? l0 * jc[j] : kZ && j == 4 ? l1 * jc[ND + j] : l0 * jc[j] + l1 * jc[ND + j];
+        }
+        const double w0 = a[0] * s0.x + a[1] * s0.y + a[2] * s0.z;
+        const double w1 = b[0] * s0.x + b[1] * s0.y + b[2] * s0.z;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            acc[NU + i] += jc[i] * ru + jc[ND + i] * rv;
+            acc[NU + 2 * ND + i] += jc[i] * w0 + jc[ND + i] * w1;
+        }
+    }
+    double tot[(NF + 13) / 14];
+    wave_sum_lds<NF, 14>(acc, lds + (threadIdx.x >> 6) * (64 * 16), lane, tot);
+    if (lane < 14) {
+        double* o = d.chunk_part + NF * (size_t)q;
+#pragma unroll
+        for (int p = 0; p < (NF + 13) / 14; ++p)
+            if (14 * p + lane < NF) o[14 * p + lane] = tot[p];
+    }
+}
+
+// thread = (camera, entry of the UG row followed by the T row): chunk sums in fixed order
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_chunk_reduce_fused(Dev d, double* __restrict__ tpart) {
+    constexpr int ND = M::ND, NU = M::NU, NV = M::NV, NF = NU + 3 * ND;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= d.n_cam * 2 * NV) return;
+    const int c = i / (2 * NV), v = i - c * (2 * NV);
+    int src = -1;                                   // column of the chunk rows, -1: a zero of the T row
+    if (v < NV) src = v;
+    else if (v - NV >= NU) src = NU + 2 * ND + (v - NV - NU);
+    else {
+#pragma unroll
+        for (int r = 0; r < ND; ++r)
+            if (v - NV == upidx(ND, r, r)) src = NU + ND + r;
+    }
+    double s = 0.0;
+    if (src >= 0)
+        for (int q = d.cam_chunk_ptr[c]; q < d.cam_chunk_ptr[c + 1]; ++q) s += d.chunk_part[(size_t)q * NF + src];
+    if (v < NV) d.UG[NV * (size_t)c + v] = s;
+    else tpart[NV * (size_t)c + (v - NV)] = s;
+}
+
 // Per camera: Minv = (U + lambda D - T)^-1, rhs = -g_c + T[NU..].
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_precond(Dev d, double lambda) {
@@ -768,6 +877,11 @@ void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only) {
 }
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st) {
     hipLaunchKernelGGL(k_chunk_reduce, dim3(cdiv(d.n_cam * nvals, kBlock)), dim3(kBlock), 0, st, d, nvals, out);
+}
+int lin_sdiag_values(int model) { return model == MODEL_BAL ? Bal::NU + 3 * Bal::ND : Pinhole::NU + 3 * Pinhole::ND; }
+void launch_lin_sdiag_cm(const Dev& d, double* tpart, hipStream_t st) {
+    if (d.n_chunks > 0) SFMBA_LAUNCH(d, k_lin_sdiag_cm, dim3(blocks_chunk(d)), st, d);
+    SFMBA_LAUNCH(d, k_chunk_reduce_fused, dim3(cdiv(d.n_cam * 2 * cam_sums(d.model), kBlock)), st, d, tpart);
 }
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st) {
     if (d.n_pts == 0) return;
