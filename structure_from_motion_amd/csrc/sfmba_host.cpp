@@ -1829,6 +1829,10 @@ int sfmba_linearize(sfmba_handle* h, double lambda) {
 int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, double* g_pt) {
     return guarded(h, [&] {
         need_linearized(h, "sfmba_get_blocks");
+        // (inside a solve the camera sums are formed in one pass and U_c is not kept on its own)
+        if (h->cm_lambda >= 0.0 && (U || g_cam)) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_get_blocks: call sfmba_linearize first");
+        // (nor are V_p and g_p stored when the points were damped in the linearisation pass)
+        if (!h->have_v && (V || g_pt)) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_get_blocks: call sfmba_linearize first");
         if (U || g_cam) {
             const int cd = h->cd, cv = h->cv;
             std::vector<double> ug((size_t)h->n_cam * cv);

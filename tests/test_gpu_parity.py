@@ -386,3 +386,17 @@ def test_host_thread_count_of_the_setup_does_not_change_the_result(monkeypatch):
             out.append((st.final_cost, st.iterations, st.pcg_iterations) + eng.get_params())
     assert out[0][:3] == out[1][:3]
     assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
+
+
+def test_blocks_cannot_be_read_from_inside_a_solve():
+    # a solve that runs out of iterations leaves a linearisation whose U_c and V_p were never
+    # stored on their own: the diagnostic refuses instead of handing out something else
+    g = load_golden(golden_names()[0])
+    with make_engine(g, max_iterations=2, linear_solver=1, schur_mode=2) as eng:
+        st = eng.solve()
+        assert st.iterations == 2
+        with pytest.raises(EngineError, match="sfmba_linearize"):
+            eng.get_blocks()
+        eng.linearize(1e-4)
+        U, gc, V, gp = eng.get_blocks()
+        assert np.isfinite(U).all() and np.isfinite(V).all()
