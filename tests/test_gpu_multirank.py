@@ -85,6 +85,24 @@ def test_sharded_two_level_solve():
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("solver", ["pcg-explicit", "pcg-explicit-stepwise", "pcg-implicit"])
+def test_sharded_solve_with_rejected_steps(solver):
+    # rejected steps re-damp without a new linearisation; with the explicit matrix that repeats the
+    # camera-major pass and its collective on every rank
+    p = syn.make_problem(12, 300, 1500, seed=4, window=8, point_sigma=0.8, rot_sigma=0.3, trans_sigma=0.5)
+    opts = dict(initial_lambda=1e-12, ftol=1e-10, **SOLVERS[solver])
+    with E.Engine(**opts) as eng:
+        eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
+                        p["points_2d"], p["K"])
+        ref = eng.solve()
+    assert ref.iterations > ref.accepted >= 5
+    out = solve_sharded(p, 2, **opts)
+    for st, _, _ in out:
+        assert st["iterations"] == ref.iterations and st["accepted"] == ref.accepted
+        assert abs(st["final_cost"] - ref.final_cost) <= 1e-8 * ref.final_cost
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
 def test_sharded_solve_larger_problem():
     p = syn.make_shape("venice", seed=1, scale=0.02)
     with E.Engine() as eng:
