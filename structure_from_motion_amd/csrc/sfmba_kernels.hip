@@ -243,8 +243,15 @@ __global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
     double acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    // (9-number camera, two wavefronts per SIMD: the point index of the next round is requested
+    // while this round's gather is in flight)
+    constexpr bool kAhead = ND > 6;
+    int pn = kAhead && k0 + lane < k1 ? d.cm_pt[k0 + lane] : 0;
     for (int k = k0 + lane; k < k1; k += 64) {
-        double4 X = d.X[d.cm_pt[k]];
+        int p;
+        if constexpr (kAhead) { p = pn; if (k + 64 < k1) pn = d.cm_pt[k + 64]; }
+        else p = d.cm_pt[k];
+        double4 X = d.X[p];
         const Seed s = M::seed(cam, X.x, X.y, X.z);
         const typename M::Obs ob = M::obs(s, cam, d.K);
         double2 uv = d.cm_uv[k];
@@ -320,8 +327,12 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
     double acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    constexpr bool kAhead = ND > 6;         // as in k_lin_cm
+    int pn = kAhead && k0 + lane < k1 ? d.cm_pt[k0 + lane] : 0;
     for (int k = k0 + lane; k < k1; k += 64) {
-        const int p = d.cm_pt[k];
+        int p;
+        if constexpr (kAhead) { p = pn; if (k + 64 < k1) pn = d.cm_pt[k + 64]; }
+        else p = d.cm_pt[k];
         Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
         const typename M::Obs ob = M::obs(s, cam, d.K);
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
