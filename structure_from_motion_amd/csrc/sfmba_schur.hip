@@ -39,27 +39,42 @@ __device__ __forceinline__ void schur_pairs_rows(const Dev& d, int q, int lane, 
     double acc[NN];
 #pragma unroll
     for (int i = 0; i < NN; ++i) acc[i] = 0.0;
-    // 9 x 9 blocks: the indices of the next round are requested while this round's gathers are in
-    // flight (530 -> 470 us per launch at the Venice shape; with 6 x 6 blocks, where three
-    // wavefronts per SIMD already overlap the two rounds of latency, the same change costs 25 %)
+    // 9 x 9 blocks: a software pipeline over the rounds, this round's arithmetic overlapping the
+    // next round's gathers (530 -> 440 us per launch at the Venice shape; with 6 x 6 blocks, where
+    // three wavefronts per SIMD already overlap the two rounds of latency, requesting the indices
+    // ahead alone costs 25 %)
     constexpr bool kAhead = ND > 6;
-    int nja = 0, njb = 0, np_ = 0;
-    if (kAhead && k0 + lane < k1) { nja = d.pair_a[k0 + lane]; njb = d.pair_b[k0 + lane]; np_ = d.pair_p[k0 + lane]; }
-    for (int k = k0 + lane; k < k1; k += 64) {
-        int ja, jb, p;
-        if constexpr (kAhead) {
-            ja = nja; jb = njb; p = np_;
-            if (k + 64 < k1) { nja = d.pair_a[k + 64]; njb = d.pair_b[k + 64]; np_ = d.pair_p[k + 64]; }
-        } else {
-            ja = d.pair_a[k]; jb = d.pair_b[k]; p = d.pair_p[k];
-        }
+    struct Gathered { Seed sa, sb; double2 v01, v23, v45; };
+    auto gather = [&](int ja, int jb, int p) {
         // seeds from the camera-major arrays: the observations of one camera are sorted by point
         // there, so neighbouring pairs of a block read neighbouring words (several per cache line)
-        Seed sa, sb;
-        sa.x = d.cm_sx[ja]; sa.y = d.cm_sy[ja]; sa.iz = d.cm_siz[ja];
-        sb.x = d.cm_sx[jb]; sb.y = d.cm_sy[jb]; sb.iz = d.cm_siz[jb];
+        Gathered g;
+        g.sa.x = d.cm_sx[ja]; g.sa.y = d.cm_sy[ja]; g.sa.iz = d.cm_siz[ja];
+        g.sb.x = d.cm_sx[jb]; g.sb.y = d.cm_sy[jb]; g.sb.iz = d.cm_siz[jb];
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
-        const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+        g.v01 = vi[0]; g.v23 = vi[1]; g.v45 = vi[2];
+        return g;
+    };
+    // kAhead: indices two rounds ahead, gathered values one round ahead
+    const int kf = k0 + lane;
+    int nja = 0, njb = 0, np_ = 0;
+    Gathered gn{};
+    if (kAhead) {
+        if (kf < k1) gn = gather(d.pair_a[kf], d.pair_b[kf], d.pair_p[kf]);
+        if (kf + 64 < k1) { nja = d.pair_a[kf + 64]; njb = d.pair_b[kf + 64]; np_ = d.pair_p[kf + 64]; }
+    }
+    for (int k = kf; k < k1; k += 64) {
+        Gathered g;
+        if constexpr (kAhead) {
+            g = gn;
+            const int ja = nja, jb = njb, p = np_;
+            if (k + 128 < k1) { nja = d.pair_a[k + 128]; njb = d.pair_b[k + 128]; np_ = d.pair_p[k + 128]; }
+            if (k + 64 < k1) gn = gather(ja, jb, p);
+        } else {
+            g = gather(d.pair_a[k], d.pair_b[k], d.pair_p[k]);
+        }
+        const Seed sa = g.sa, sb = g.sb;
+        const double2 v01 = g.v01, v23 = g.v23, v45 = g.v45;
         const typename M::Obs oa = M::obs(sa, camr, d.K), ob = M::obs(sb, camc, d.K);
         double aa[3], ab[3], ba[3], bb[3];
         M::jac_pt(oa, camr.q, aa, ab);     // rows of Jp_a
