@@ -8,8 +8,11 @@ xtol=1e-12) from the same start, with every input already resident in HBM.  Repo
 observations x LM iterations per second over the K timed steps (whole job, max over ranks),
 plus LM iterations/s, the HBM-roofline fraction of the dominant kernel (HIP-event timed) and
 SciPy's least_squares on the host cores on a bounded sample of the same workload.
-For N > 1 launch with torch.distributed.run; ranks shard the points (strong scaling of the fixed
-problem) and exchange per-camera partial sums through RCCL inside libsfmba.
+With --gpus N > 1 and no WORLD_SIZE in the environment this process touches no GPU: it starts N
+rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each) and rank 0
+prints the line; under torch.distributed.run the ranks are already there and --gpus must equal
+WORLD_SIZE.  Ranks shard the points (strong scaling of the fixed problem) and exchange per-camera
+partial sums through RCCL inside libsfmba.
 """
 import argparse
 import json
@@ -71,6 +74,31 @@ def cpu_baseline(scale, seed, camera_model="pinhole"):
     }
 
 
+def spawn_ranks(n):
+    """Parent of an N-rank run: start the ranks as fresh child processes before anything here has
+    touched a GPU (counting devices does not), pass rank 0's line through, fail if any rank fails."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} asked for but this machine shows {have} GPU(s); "
+                         f"not falling back to fewer\n")
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +118,16 @@ def main():
                     help="pinhole: the 12-number camera of bundle_adjustment.py (the headline workload); "
                          "bal: the 9-number camera of ba_test.py on the same scene")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            spawn_ranks(args.gpus)          # does not return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: "
+                         f"launch as many ranks as --gpus names\n")
+        sys.exit(2)
 
     import torch
     from structure_from_motion_amd import synthetic as syn
@@ -155,71 +193,89 @@ def main():
     n_obs = p["n_obs"]
     last = stats[-1]
 
-    # per-kernel timing from one more solve with HIP events around every launch (same stream).
-    # PCG launches queued after convergence return at once; their (few) microseconds stay in
-    # the totals and the per-launch average of the PCG kernels is taken over the iterations
-    # that did work, so it errs on the slow side.
-    roof, families = None, None
+    # per-kernel timing from one more solve of the same engine with HIP events around every launch
+    # (same stream; on every rank, since the collectives of a solve need all of them).  PCG
+    # launches queued after convergence return at once; their (few) microseconds stay in the
+    # totals and the per-launch average of the PCG kernels is taken over the iterations that did
+    # work, so it errs on the slow side.
+    os.environ["SFMBA_PROFILE"] = "1"
+    eng.reset_params()
+    ps = eng.solve()
+    os.environ["SFMBA_PROFILE"] = "0"
+    # this rank's partition (the whole problem on one GPU)
+    from structure_from_motion_amd.distributed import point_partition
+    lo, hi = point_partition(p["point_indices"], p["n_points"], rank, world) if world > 1 else (0, p["n_points"])
+    mine = (p["point_indices"] >= lo) & (p["point_indices"] < hi)
+    my_obs, my_pts = int(mine.sum()), hi - lo
+    chunk = int(os.environ.get("SFMBA_CHUNK", "512"))
+    cam_counts = np.bincount(p["camera_indices"][mine], minlength=p["n_cameras"])
+    n_chunks = int(np.sum((cam_counts + chunk - 1) // chunk))
+    ab = algorithmic_bytes(my_obs, my_pts, p["n_cameras"], n_chunks, ps.schur_pairs, ps.schur_chunks,
+                           cam_dim=9 if bal else 6)
+    if ps.pcg_single_launch:
+        # single-launch PCG: the matrix lives in registers; one iteration moves the 18-word
+        # record of every gathered column and of every row written (through memory, past L2)
+        ab["bsr"] = 144 * ps.schur_blocks + 144 * p["n_cameras"]
+    else:
+        cd = 9 if bal else 6
+        ab["bsr"] = (8 * cd * cd + 4) * ps.schur_blocks + 40 * cd * p["n_cameras"]
+    families = {}
+    for fam in ("linearize", "damp", "schur", "pairs", "bsr", "spmv_pm", "spmv_cm", "pcg_vec", "back", "cost", "dense", "comm"):
+        n = getattr(ps, "n_" + fam)
+        ms = getattr(ps, "ms_" + fam)
+        eff = int(ps.pcg_iterations) if fam in ("bsr", "spmv_pm", "spmv_cm") and n else int(n)
+        families[fam] = {"launches": int(n), "effective_launches": eff, "total_ms": ms,
+                         "avg_us": 1e3 * ms / eff if eff else 0.0}
     if world == 1:
-        prof_eng = Engine(device=local_rank, profile=1, **solver_opts)
-        prof_eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
-                             p["points_2d"], p["K"])
-        prof_eng.solve()
-        prof_eng.reset_params()
-        ps = prof_eng.solve()
-        chunk = int(os.environ.get("SFMBA_CHUNK", "512"))
-        cam_counts = np.bincount(p["camera_indices"], minlength=p["n_cameras"])
-        n_chunks = int(np.sum((cam_counts + chunk - 1) // chunk))
-        ab = algorithmic_bytes(n_obs, p["n_points"], p["n_cameras"], n_chunks, ps.schur_pairs, ps.schur_chunks,
-                               cam_dim=9 if bal else 6)
-        if ps.pcg_single_launch:
-            # single-launch PCG: the matrix lives in registers; one iteration moves the 18-word
-            # record of every gathered column and of every row written (through memory, past L2)
-            ab["bsr"] = 144 * ps.schur_blocks + 144 * p["n_cameras"]
-        else:
-            cd = 9 if bal else 6
-            ab["bsr"] = (8 * cd * cd + 4) * ps.schur_blocks + 40 * cd * p["n_cameras"]
-        families = {}
-        for fam in ("linearize", "damp", "schur", "pairs", "bsr", "spmv_pm", "spmv_cm", "pcg_vec", "back", "cost", "dense"):
-            n = getattr(ps, "n_" + fam)
-            ms = getattr(ps, "ms_" + fam)
-            eff = int(ps.pcg_iterations) if fam in ("bsr", "spmv_pm", "spmv_cm") and n else int(n)
-            families[fam] = {"launches": int(n), "effective_launches": eff, "total_ms": ms,
-                             "avg_us": 1e3 * ms / eff if eff else 0.0}
-        single = [f for f in ("pairs", "bsr", "spmv_pm", "spmv_cm") if families[f]["launches"]]
-        # the kernel that streams the observations inside the linear solve: the explicit Schur
-        # assembly, or (implicit mode) the point-major half of the matvec
-        dom = "pairs" if ps.schur_mode == 2 else "spmv_pm"
+        del families["comm"]
+    single = [f for f in ("pairs", "bsr", "spmv_pm", "spmv_cm") if families[f]["launches"]]
+    # the kernel that streams the observations inside the linear solve: the explicit Schur
+    # assembly, or (implicit mode) the point-major half of the matvec
+    dom = "pairs" if ps.schur_mode == 2 else "spmv_pm"
 
-        def price(f):
-            avg_s = families[f]["avg_us"] * 1e-6
-            return ab[f] / avg_s / 1e9 if avg_s > 0 else 0.0
+    def price(f):
+        avg_s = families[f]["avg_us"] * 1e-6
+        return ab[f] / avg_s / 1e9 if avg_s > 0 else 0.0
 
-        kernel_name = {"pairs": "k_schur_pairs", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm",
-                       "bsr": "k_pcg_fused (per PCG iteration)" if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0 and not bal:
-            with open(tpath) as f:
-                recorded = json.load(f).get("kernels", {})
-            for name, rec in recorded.items():          # template arguments follow the name: k_schur_pairs<Pinhole>
-                if name.split("<")[0] == kernel_name[dom]:
-                    traffic = rec.get("hbm_bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": kernel_name[dom], "achieved": price(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": price(dom) / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": families[dom]["avg_us"],
-                "launches_per_solve": families[dom]["effective_launches"],
-                "other_kernels": {kernel_name[f]: {"algorithmic_bytes_per_launch": ab[f],
-                                                   "avg_launch_us": families[f]["avg_us"], "achieved": price(f)}
-                                  for f in single if f != dom},
-                "schur_mode": "explicit" if ps.schur_mode == 2 else "implicit",
-                "schur_pairs": int(ps.schur_pairs), "schur_blocks": int(ps.schur_blocks)}
-        prof_eng.close()
+    kernel_name = {"pairs": "k_schur_pairs", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm",
+                   "bsr": "k_pcg_fused (per PCG iteration)" if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0 and not bal and world == 1:
+        with open(tpath) as f:
+            recorded = json.load(f).get("kernels", {})
+        for name, rec in recorded.items():          # template arguments follow the name: k_schur_pairs<Pinhole>
+            if name.split("<")[0] == kernel_name[dom]:
+                traffic = rec.get("hbm_bytes_per_launch")
+    roof = {"bound": "hbm", "kernel": kernel_name[dom], "achieved": price(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": price(dom) / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": families[dom]["avg_us"],
+            "launches_per_solve": families[dom]["effective_launches"],
+            "other_kernels": {kernel_name[f]: {"algorithmic_bytes_per_launch": ab[f],
+                                               "avg_launch_us": families[f]["avg_us"], "achieved": price(f)}
+                              for f in single if f != dom},
+            "schur_mode": "explicit" if ps.schur_mode == 2 else "implicit",
+            "schur_pairs": int(ps.schur_pairs), "schur_blocks": int(ps.schur_blocks)}
+    multi = None
+    if world > 1:
+        # rank 0's partition and kernels; what does not shrink with the rank count is the PCG on the
+        # replicated reduced system and the collectives
+        roof["rank"] = 0
+        roof["partition"] = {"points": my_pts, "observations": my_obs}
+        multi = {"collectives_per_solve": families["comm"]["launches"],
+                 "collective_ms_per_solve": families["comm"]["total_ms"],
+                 "replicated_pcg_ms_per_solve": families["bsr"]["total_ms"] + families["pcg_vec"]["total_ms"]
+                 if ps.schur_mode == 2 else None,
+                 "profiled_solve_ms": 1e3 * ps.solve_seconds}
+
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_scale, args.seed, args.camera_model)
 
     if rank == 0:
@@ -248,12 +304,12 @@ def main():
             "solve_seconds": elapsed / args.steps,
             "initial_cost": last.initial_cost, "final_cost": last.final_cost, "status": last.status,
             "setup_seconds": setup_s,
+            "pcg_single_fallbacks_per_solve": sum(s.pcg_single_fallbacks for s in stats) / args.steps,
             "roofline": roof, "kernels": families, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        if multi is not None:
+            out["multi_gpu"] = multi
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -144,6 +144,7 @@ typedef struct sfmba_stats {
     int64_t pcg_single_fallbacks;              /* single-launch solves redone launch by launch */
     int64_t pcg_coarse_solves;                 /* linear solves preconditioned with the coarse space */
     int64_t pcg_coarse_dim;                    /* coarse unknowns (7 x clusters), 0 = no coarse space built */
+    double ms_comm;       int64_t n_comm;      /* all-reduces between the ranks (stream time: the wait for the slowest rank included) */
 } sfmba_stats;
 
 /* Fill *opts with the defaults listed above. */

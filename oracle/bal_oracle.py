@@ -3,12 +3,13 @@
 file format.  TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module; the shipped package never does.
 
-PARITY UNPINNED: the reference script that holds this model (/root/reference/ba_test.py) fetches
-its input over the network when imported (ba_test.py:9-14), so it was not run, and the reference
-keeps neither the data file nor any expected output.  Everything below is a restatement of that
-script's NumPy arithmetic, checked only against itself, SciPy and hand-made files.  The optimiser
-is not restated: `solve_reference` drives the real scipy.optimize.least_squares with the
-script's keyword arguments (ba_test.py:125-126).
+PINNED against the reference itself: /root/reference/ba_test.py fetches its input over the network
+when imported unless a file of the right name lies in the working directory (ba_test.py:9-14);
+oracle/gen_golden_bal_ref.py imports it in the build container on local data files and stores what
+the module computed in tests/golden/bal_ref_*.npz (reader outputs, rotate / project / fun, the
+pattern, its least_squares result).  tests/test_oracle_bal.py requires this restatement to
+reproduce those files bit for bit.  The optimiser is not restated: `solve_reference` drives the
+real scipy.optimize.least_squares with the script's keyword arguments (ba_test.py:125-126).
 
 What is restated, and from where:
   read_bal_data()               /root/reference/ba_test.py:17-42   (one readline per number)
@@ -70,7 +71,7 @@ def project(points, camera_params):
         p = -P[:, :2] / P[:, 2:3]
     f, k1, k2 = camera_params[:, 6], camera_params[:, 7], camera_params[:, 8]
     n = np.sum(p * p, axis=1)
-    return p * (f * (1.0 + k1 * n + k2 * n * n))[:, None]
+    return p * ((1.0 + k1 * n + k2 * (n * n)) * f)[:, None]      # k2 (n^2), then the sum, then f: the reference's rounding
 
 
 def fun(params, n_cameras, n_points, camera_indices, point_indices, points_2d):

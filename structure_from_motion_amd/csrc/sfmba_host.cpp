@@ -182,16 +182,25 @@ struct LocalGroup {
     std::vector<double*> bufs;
     std::vector<size_t> counts;
     std::vector<int> devices;
-    bool failed = false;
-    void barrier() {
+    bool failed = false;      // written by rank 0 between two barriers, read by the others after the second
+    bool aborted = false;     // a member failed outside a collective: nobody waits for it any more
+    // Returns false when the group was aborted (before or while waiting).
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
         const long gen = generation;
         if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else cv.wait(lk, [&] { return generation != gen || aborted; });
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
-enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_PAIRS, F_COUNT };
+enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_PAIRS, F_COMM, F_COUNT };
 
 }  // namespace
 
@@ -243,7 +252,7 @@ struct sfmba_handle {
     DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
     DBuf<double> pair_part, Bsum, Sfull;
     // single-launch PCG on the scaled system
-    bool fused_pcg = false, fused_armed = false, fused_cooperative = false, fused_refused = false;
+    bool fused_pcg = false, fused_armed = false, fused_refused = false;
     int fused_blocks = 0;
     int64_t fused_solves = 0, fused_fallbacks = 0;
     DBuf<double> Shat, Fscale, bhat, fvec;    // fvec: generation records, p, xh
@@ -372,14 +381,15 @@ void collect_spans(H* h) {
 
 // ---- collectives --------------------------------------------------------------------------
 void allreduce(H* h, double* buf, size_t count) {
-    if (count == 0) return;
+    if (count == 0 || !h->has_comm()) return;
+    Scope t(h, F_COMM);
     if (h->group) {
         LocalGroup* g = h->group;
         const int rk = h->opt.rank;
         HIP_TRY(hipStreamSynchronize(h->stream));
         g->bufs[rk] = buf;
         g->counts[rk] = count;
-        g->barrier();
+        if (!g->barrier()) fail(SFMBA_ERR_COMM, "in-process group aborted: another member failed");
         if (rk == 0) {                       // fixed rank order: bitwise reproducible
             hipError_t e = hipSuccess;
             for (int r = 1; r < g->n; ++r)   // ranks out of step: refuse before touching memory
@@ -395,7 +405,7 @@ void allreduce(H* h, double* buf, size_t count) {
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             g->failed = e != hipSuccess;
         }
-        g->barrier();
+        if (!g->barrier()) fail(SFMBA_ERR_COMM, "in-process group aborted: another member failed");
         if (g->failed) fail(SFMBA_ERR_COMM, "in-process all-reduce failed");
         return;
     }
@@ -545,7 +555,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
             Scope t(h, F_BSR);
             // (plain launch: grids of several handles that meet on one GPU can keep each other from
             // becoming resident; the admission timeout then sends those solves to the fallback)
-            e = launch_pcg_fused(f, h->fused_armed, h->fused_cooperative, h->stream);
+            e = launch_pcg_fused(f, h->fused_armed, h->stream);
             h->fused_armed = false;
         }
         PcgState st{};
@@ -687,29 +697,39 @@ int phase_linear_solve(H* h, double lambda, bool allow_fused = true) {
     return st.iter;
 }
 
+// What a rank whose single launch was refused puts into the flag slot: larger than any sum of the
+// kernel's own flags (1 breakdown, 2 timeout) over 64 ranks.
+constexpr double kPcgRefused = 1024.0;
+
 // Single-launch PCG without waiting for its outcome: its flag goes into a scalar slot that
 // travels (and, with a communicator, is summed over the ranks) with the scalars of the trial step,
 // its state into pinned host memory; both are looked at after the trial step, which saves a host
 // synchronisation and, between ranks, a collective per LM iteration.  Returns false when the solve
 // has to take the synchronous route (other solver, launch refused earlier).
 bool launch_linear_solve_async(H* h) {
-    if (!(h->explicit_schur && h->fused_pcg && !h->fused_refused && !h->use_dense)) return false;
+    if (!(h->explicit_schur && h->fused_pcg && !h->use_dense)) return false;
+    if (h->fused_refused && !h->has_comm()) { h->fused_pcg = false; return false; }
     const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
     FusedPcg& f = h->fused;
     f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     f.flag_slot = h->scalars.p + SLOT_PCGFLAG;
-    hipError_t e;
-    {
+    hipError_t e = hipErrorNotSupported;
+    if (!h->fused_refused) {
         Scope t(h, F_BSR);
-        e = launch_pcg_fused(f, h->fused_armed, h->fused_cooperative, h->stream);
+        e = launch_pcg_fused(f, h->fused_armed, h->stream);
         h->fused_armed = false;
     }
     if (e != hipSuccess) {
-        // refused on this rank: tell the others through the flag, take the synchronous route from now on
+        // Refused on this rank.  Which route a solve takes must be the same decision on every rank
+        // (the routes issue different collectives), so this rank stays on this one and reports
+        // kPcgRefused through the flag slot, which is summed over the ranks with the scalars of the
+        // trial step: every rank then redoes this solve launch by launch and gives the single
+        // launch up for good (do_solve).
         (void)hipGetLastError();
+        if (!h->has_comm()) { h->fused_refused = true; h->fused_pcg = false; return false; }
         h->fused_refused = true;
-        const double one = 1.0;
-        HIP_TRY(hipMemcpyAsync(h->scalars.p + SLOT_PCGFLAG, &one, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const double v = kPcgRefused;
+        HIP_TRY(hipMemcpyAsync(h->scalars.p + SLOT_PCGFLAG, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
@@ -743,10 +763,12 @@ double read_lin_scalars(H* h, double* sc) {
 
 void print_header() {
     printf("%s\n", "   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality   ");
+    fflush(stdout);
 }
 void print_row(int it, int nfev, double cost, double red, double step, double opt, bool first) {
     if (first) printf("%8d     %10d      %13.4e                                 %10.2e    \n", it, nfev, cost, opt);
     else printf("%8d     %10d      %13.4e    %10.2e     %10.2e     %10.2e    \n", it, nfev, cost, red, step, opt);
+    fflush(stdout);     // rows appear in order with whatever the caller prints itself
 }
 
 void do_solve(H* h, sfmba_stats* out) {
@@ -810,6 +832,7 @@ void do_solve(H* h, sfmba_stats* out) {
             if (h->trace_pcg)
                 fprintf(stderr, "pcg single launch: %d iterations, %.2f us in kernel, flag %d (all ranks %g)\n", ps.iter, ps.ticks * 0.01, ps.pad, sc[SLOT_PCGFLAG]);
             const bool failed = sc[SLOT_PCGFLAG] != 0.0;
+            if (sc[SLOT_PCGFLAG] >= kPcgRefused) h->fused_pcg = false;     // on every rank alike
             const bool converged = !(ps.rz > ps.tol2 * ps.rz0);
             if (!failed && (converged || !h->dense_allowed)) {
                 h->fused_solves++;
@@ -836,7 +859,7 @@ void do_solve(H* h, sfmba_stats* out) {
         const bool ft = actual < ftol * cost && rho > 0.25;
         const bool xt = step_norm < xtol * (xtol + x_norm);
         if (o.verbose >= 3 && o.rank <= 0)
-            printf("  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e\n", it, cost, cost_new, rho, lambda, step_norm);
+            { printf("  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e\n", it, cost, cost_new, rho, lambda, step_norm); fflush(stdout); }
         if (rho > 1e-3) {
             h->cur ^= 1;
             ++accepted;
@@ -888,6 +911,7 @@ void do_solve(H* h, sfmba_stats* out) {
     st.schur_blocks = h->explicit_schur ? h->nnzb : 0;
     st.schur_chunks = h->explicit_schur ? h->n_pchunks : 0;
     st.ms_pairs = h->fam_ms[F_PAIRS]; st.n_pairs = h->fam_n[F_PAIRS];
+    st.ms_comm = h->fam_ms[F_COMM]; st.n_comm = h->fam_n[F_COMM];
     st.pcg_single_launch = h->fused_solves; st.pcg_single_fallbacks = h->fused_fallbacks;
     st.pcg_coarse_solves = h->coarse_solves;
     st.pcg_coarse_dim = h->explicit_schur && h->coarse_built ? h->coarse.n : 0;
@@ -899,6 +923,7 @@ void do_solve(H* h, sfmba_stats* out) {
                                     "Both `ftol` and `xtol` termination conditions are satisfied."};
         printf("%s\nFunction evaluations %d, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n",
                msg[status], st.nfev, st.initial_cost, st.final_cost, st.optimality);
+        fflush(stdout);
     }
     if (out) *out = st;
 }
@@ -1269,10 +1294,11 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
             f.timeout_ticks = 20000000LL;         // 0.2 s of the 100 MHz wall clock
             f.admit_ticks = 200000LL;             // 2 ms
             f.blocks = blocks;
-            h->fused_cooperative = getenv("SFMBA_PCG_COOPERATIVE") != nullptr && atoi(getenv("SFMBA_PCG_COOPERATIVE")) != 0;
             h->fused_blocks = blocks;
             h->fused_pcg = true;
             h->fused_refused = false;
+            // test hook: the launch counts as refused on this rank of a partitioned solve
+            if (const char* e = getenv("SFMBA_PCG_REFUSE_RANK")) h->fused_refused = h->opt.nranks > 1 && atoi(e) == h->opt.rank;
         }
     }
     // Coarse space of the two-level preconditioner: clusters of consecutive cameras, never smaller
@@ -1564,22 +1590,27 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
 template <class F>
 int guarded(sfmba_handle* h, F&& f) {
     if (!h) return SFMBA_ERR_INVALID_ARGUMENT;
+    int code = SFMBA_OK;
     try {
         f();
         return SFMBA_OK;
     } catch (const ApiError& e) {
         h->err = e.msg;
-        return e.code;
+        code = e.code;
     } catch (const HipError& e) {
         h->err = std::string(e.what) + ": " + hipGetErrorString(e.e);
-        return SFMBA_ERR_HIP;
+        code = SFMBA_ERR_HIP;
     } catch (const std::bad_alloc&) {
         h->err = "out of host memory";
-        return SFMBA_ERR_INVALID_ARGUMENT;
+        code = SFMBA_ERR_INVALID_ARGUMENT;
     } catch (...) {
         h->err = "unexpected exception";
-        return SFMBA_ERR_INVALID_ARGUMENT;
+        code = SFMBA_ERR_INVALID_ARGUMENT;
     }
+    // a member of an in-process group that fails would leave the others waiting in their next
+    // collective for ever: wake them, they fail with SFMBA_ERR_COMM
+    if (h->group) h->group->abort();
+    return code;
 }
 
 void need_problem(H* h, const char* who) {
@@ -1990,7 +2021,7 @@ int sfmba_comm_init_local(sfmba_handle* h, void* group) {
             std::lock_guard<std::mutex> lk(g->m);
             g->devices[h->opt.rank] = h->device;
         }
-        g->barrier();
+        if (!g->barrier()) fail(SFMBA_ERR_COMM, "in-process group aborted: another member failed");
         // every pair of devices in the group must be able to address each other's memory
         for (int r = 0; r < g->n; ++r) {
             if (g->devices[r] == h->device) continue;

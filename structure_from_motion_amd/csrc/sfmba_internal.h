@@ -193,9 +193,8 @@ int pcg_fused_max_blocks(int device);
 int pcg_fused_rows_per_block();
 size_t pcg_fused_record_words(int blocks);
 size_t pcg_fused_vector_words(int n_cam);
-// `armed`: the records already hold the sentinel (k_finish_diag did it); `cooperative`: ask the
-// runtime for guaranteed co-residency (costs tens of microseconds per launch)
-hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, bool cooperative, hipStream_t st);
+// `armed`: the records already hold the sentinel (k_finish_diag did it)
+hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);

@@ -295,9 +295,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_
 // write-back or invalidation, and the matrix stays in registers (or L2).  Workgroup-internal
 // barriers order LDS traffic only and never wait for those stores.
 //
-// The grid must be co-resident: one workgroup per compute unit at most, launched either with the
-// runtime's cooperative guarantee or plainly (an otherwise idle device schedules all of them at
-// once).  A poll that exceeds its time limit - admit_ticks for the first one, which waits for every
+// The grid must be co-resident: one workgroup per compute unit at most, launched plainly (an
+// otherwise idle device schedules all of them at once; the runtime's cooperative launch, which
+// would guarantee it, costs tens of microseconds per launch and goes through a queue of its own
+// that the runtime tears down at process exit).  A poll that exceeds its time limit - admit_ticks for the first one, which waits for every
 // workgroup to show up, timeout_ticks afterwards - clears the abort word, which every polling
 // wavefront checks, so the grid always drains; the caller then solves launch by launch.
 constexpr int kFusedThreads = 512;
@@ -715,9 +716,9 @@ size_t pcg_fused_record_words(int blocks) { return 2 * kSlots * (size_t)blocks +
 size_t pcg_fused_vector_words(int n_cam) { return kSlots * (size_t)n_cam * kVecRec; }
 
 // Arms every record (all bits set) and the abort word unless that has been done, then launches
-// the solve.  Without the cooperative guarantee the kernel relies on its admission timeout: a
-// grid that does not become fully resident within admit_ticks aborts and the caller falls back.
-hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, bool cooperative, hipStream_t st) {
+// the solve.  The launch is a plain one and the kernel relies on its admission timeout: a grid
+// that does not become fully resident within admit_ticks aborts and the caller falls back.
+hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st) {
     if (!armed) {
         hipError_t e = hipMemsetAsync(f.dots, 0xFF, pcg_fused_record_words(f.blocks) * sizeof(unsigned long long), st);
         if (e != hipSuccess) return e;
@@ -725,10 +726,6 @@ hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, bool cooperative, hip
         if (e != hipSuccess) return e;
     }
     FusedPcg arg = f;
-    if (cooperative) {
-        void* params[] = {&arg};
-        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_pcg_fused), dim3(f.blocks), dim3(kFusedThreads), params, 0, st);
-    }
     hipLaunchKernelGGL(k_pcg_fused, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     return hipGetLastError();
 }

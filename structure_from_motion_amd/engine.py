@@ -75,6 +75,7 @@ class Stats(C.Structure):
         ("schur_pairs", C.c_int64), ("schur_blocks", C.c_int64), ("schur_chunks", C.c_int64),
         ("pcg_single_launch", C.c_int64), ("pcg_single_fallbacks", C.c_int64),
         ("pcg_coarse_solves", C.c_int64), ("pcg_coarse_dim", C.c_int64),
+        ("ms_comm", C.c_double), ("n_comm", C.c_int64),
     ]
 
     def as_dict(self):

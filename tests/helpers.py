@@ -29,7 +29,21 @@ def golden_names(need=None):
 
 
 def bal_golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "bal_*.npz")))
+    """Fixtures of the 9-number camera made by the oracle (oracle/gen_golden.py)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "bal_*.npz"))
+                  if not os.path.basename(p).startswith("bal_ref_"))
+
+
+# Outputs of the reference's own ba_test.py run on a local data file (oracle/gen_golden_bal_ref.py):
+# fixture name -> the data file in the published layout it was run on.
+BAL_REF_CASES = {"bal_ref_6_40": "bal_problem-6-40-pre.txt.bz2",
+                 "bal_ref_12_300": "bal_problem-12-300-pre.txt.bz2",
+                 "bal_ref_49_7776": "bal_problem-49-7776-pre.txt.bz2"}
+
+
+def load_bal_ref(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
 
 
 def load_golden(name):

@@ -1,5 +1,6 @@
 """GPU: the second camera model (9-number camera of /root/reference/ba_test.py) through the C ABI,
-against the oracle's fixtures.  Tolerances: residuals 1e-10 relative (absolute below 1 px),
+against the oracle's fixtures and against the outputs of the reference script itself
+(tests/golden/bal_ref_*.npz, made by oracle/gen_golden_bal_ref.py).  Tolerances: residuals 1e-10 relative (absolute below 1 px),
 Jacobian blocks 1e-5 of the largest entry against SciPy's finite differences, normal-equation
 blocks and the Schur product 1e-11 against NumPy sums of the engine's own Jacobian blocks, final
 cost not above SciPy's by more than 1e-6 relative, converged cost within 1e-6 relative."""
@@ -9,7 +10,7 @@ import threading
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN_DIR, bal_blocks_to_reference_jacobian, bal_golden_jacobian, bal_golden_names,
+from helpers import (BAL_REF_CASES, load_bal_ref, GOLDEN_DIR, bal_blocks_to_reference_jacobian, bal_golden_jacobian, bal_golden_names,
                      elementwise_rel, load_golden, rel_err)
 from oracle import bal_oracle as b
 from structure_from_motion_amd import bal
@@ -38,6 +39,27 @@ def test_residuals_match_golden(name):
         f = eng.residuals()
     assert f.shape == g["f0"].shape
     assert elementwise_rel(f, g["f0"], floor=1.0) <= 1e-10
+
+
+@pytest.mark.parametrize("name", list(BAL_REF_CASES))
+def test_engine_against_the_reference_script_run(name):
+    """File in, residuals and solve out, against what /root/reference/ba_test.py computed on the
+    same file: f0 (ba_test.py:121) to 1e-10, final cost not above its least_squares result
+    (ba_test.py:125-126) by more than 1e-6 relative."""
+    ref = load_bal_ref(name)
+    cams, pts, ci, pi, uv = bal.read_bal_data(os.path.join(GOLDEN_DIR, BAL_REF_CASES[name]))
+    with E.Engine(camera_model="bal") as eng:
+        eng.set_problem(cams, pts, ci, pi, uv, None)
+        f = eng.residuals()
+        assert f.shape == ref["f0"].shape
+        assert elementwise_rel(f, ref["f0"], floor=1.0) <= 1e-10
+        st = eng.solve()
+        poses, points = eng.get_params()
+    assert abs(st.initial_cost - float(ref["ref_initial_cost"])) <= 1e-10 * float(ref["ref_initial_cost"])
+    assert st.final_cost <= float(ref["ref_cost"]) * (1 + 1e-6)
+    # the reported cost is the cost of the returned parameters under the reference's model
+    prob = dict(camera_params=cams, points_3d=pts, camera_indices=ci, point_indices=pi, points_2d=uv)
+    assert abs(b.cost(prob, poses, points) - st.final_cost) <= 1e-9 * st.final_cost
 
 
 def test_fun_and_project_dropins_match_oracle():

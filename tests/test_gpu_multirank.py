@@ -43,6 +43,9 @@ def solve_sharded(p, nranks, **opts):
         t.start()
     for t in threads:
         t.join(timeout=120)
+    # a thread still inside a collective holds the group's mutex and condition variable: fail
+    # without destroying the group under it
+    assert not any(t.is_alive() for t in threads), "a rank is still running"
     E.local_group_destroy(group)
     assert not err, err
     assert all(x is not None for x in out)
@@ -101,6 +104,58 @@ def test_sharded_solve_with_rejected_steps(solver):
         assert st["iterations"] == ref.iterations and st["accepted"] == ref.accepted
         assert abs(st["final_cost"] - ref.final_cost) <= 1e-8 * ref.final_cost
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_single_launch_pcg_refused_on_one_rank(monkeypatch):
+    # the launch of the single-launch PCG counts as refused on rank 1 only: all ranks must take the
+    # same route (the routes issue different collectives), redo that solve launch by launch and
+    # give the single launch up together
+    g = load_golden("shuffled_9_200_700")
+    opts = SOLVERS["pcg-explicit"]
+    with E.Engine(**opts) as eng:
+        eng.set_problem(g["camera_params"], g["points_3d"], g["camera_indices"], g["point_indices"],
+                        g["points_2d"], g["K"])
+        ref = eng.solve()
+    monkeypatch.setenv("SFMBA_PCG_REFUSE_RANK", "1")
+    out = solve_sharded(g, 2, **opts)
+    for st, _, _ in out:
+        assert st["pcg_single_launch"] == 0 and st["pcg_single_fallbacks"] == 1
+        assert st["status"] == ref.status and st["iterations"] == ref.iterations
+        assert abs(st["final_cost"] - ref.final_cost) <= 1e-9 * ref.final_cost
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_failing_member_releases_the_group():
+    # one member fails before its first collective (an out-of-range index): the other must not
+    # wait for it for ever but fail with the library's communication error
+    g = load_golden("tiny_4_50_150")
+    group = E.local_group_create(2)
+    res = [None, None]
+
+    def work(r):
+        try:
+            with E.Engine(rank=r, nranks=2) as eng:
+                eng.set_problem(g["camera_params"], g["points_3d"], g["camera_indices"], g["point_indices"],
+                                g["points_2d"], g["K"])
+                eng.comm_init_local(group)
+                if r == 1:
+                    bad = g["camera_indices"].copy()
+                    bad[0] = 10 ** 6
+                    eng.set_problem(g["camera_params"], g["points_3d"], bad, g["point_indices"], g["points_2d"], g["K"])
+                eng.solve()
+                res[r] = "solved"
+        except Exception as e:
+            res[r] = e
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in threads)
+    E.local_group_destroy(group)
+    assert isinstance(res[1], IndexError)
+    assert isinstance(res[0], E.EngineError) and res[0].code == -5
 
 
 def test_sharded_solve_larger_problem():

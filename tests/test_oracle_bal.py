@@ -1,7 +1,10 @@
 """CPU: the oracle of the 9-number camera (/root/reference/ba_test.py) against its fixtures, and
-the package's file reader / writer against the oracle's line-by-line reader.  The reference holds
-no data file and no expected output for this script (it downloads its input), so these vectors pin
-the engine to the oracle only: parity unpinned."""
+the package's file reader / writer against the oracle's line-by-line reader.
+
+Pinned: tests/golden/bal_ref_*.npz hold what the reference's own ba_test.py computed when it was
+imported in the build container on the data files beside them (oracle/gen_golden_bal_ref.py): the
+arrays its reader returned, rotate() / project() / fun() outputs, the pattern, and the result of
+its least_squares call.  The oracle must reproduce them bit for bit (same NumPy, same SciPy)."""
 import bz2
 import os
 
@@ -9,12 +12,44 @@ import numpy as np
 import pytest
 from scipy.optimize._numdiff import approx_derivative
 
-from helpers import GOLDEN_DIR, bal_golden_jacobian, bal_golden_names, load_golden
+from helpers import BAL_REF_CASES, GOLDEN_DIR, bal_golden_jacobian, bal_golden_names, load_bal_ref, load_golden
 from oracle import bal_oracle as b
 from structure_from_motion_amd import bal
 from structure_from_motion_amd import synthetic as syn
 
 FILES = ["bal_problem-6-40-pre.txt.bz2", "bal_problem-4-10-pre.txt"]
+
+
+@pytest.mark.parametrize("name", list(BAL_REF_CASES))
+def test_oracle_equals_the_reference_script_run(name):
+    """oracle/bal_oracle.py against the outputs of /root/reference/ba_test.py itself
+    (ba_test.py:17-42 reader, :62-100 model, :103-117 pattern, :120-126 solve)."""
+    ref = load_bal_ref(name)
+    path = os.path.join(GOLDEN_DIR, BAL_REF_CASES[name])
+    cams, pts, ci, pi, uv = b.read_bal_data(path)
+    assert (cams.shape[0], pts.shape[0], ci.size) == (int(ref["n_cameras"]), int(ref["n_points"]), int(ref["n_observations"]))
+    if "camera_params" in ref:          # the reader, the rotation and the projection on their own
+        for got, key in ((cams, "camera_params"), (pts, "points_3d"), (ci, "camera_indices"), (pi, "point_indices"), (uv, "points_2d")):
+            assert got.dtype == ref[key].dtype and np.array_equal(got, ref[key]), key
+        assert np.array_equal(b.rotate(pts[pi], cams[ci][:, :3]), ref["rotated"])
+        assert np.array_equal(b.project(pts[pi], cams[ci]), ref["projected"])
+        # the package's vectorised reader returns the same arrays
+        for got, key in zip(bal.read_bal_data(path), ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d")):
+            assert np.array_equal(got, ref[key]), key
+    prob = dict(camera_params=cams, points_3d=pts, camera_indices=ci, point_indices=pi, points_2d=uv,
+                n_cameras=cams.shape[0], n_points=pts.shape[0], n_obs=ci.size)
+    x0, args = b.pack(prob)
+    assert np.array_equal(b.fun(x0, *args), ref["f0"])
+    A = b.bundle_adjustment_sparsity(*args[:4])
+    A.sort_indices()
+    assert A.shape == tuple(ref["pattern_shape"]) and A.nnz == int(ref["pattern_nnz"])
+    assert int(A.indices.astype(np.int64).sum()) == int(ref["pattern_colsum"])
+    # the script's least_squares call: same SciPy, same function values -> the same iterates
+    r = b.solve_reference(prob)
+    assert (r["status"], r["nfev"]) == (int(ref["ref_status"]), int(ref["ref_nfev"]))
+    assert abs(r["cost"] - float(ref["ref_cost"])) <= 1e-12 * float(ref["ref_cost"])
+    x = np.hstack([r["camera_params"].ravel(), r["points_3d"].ravel()])
+    assert np.abs(x - ref["ref_x"]).max() <= 1e-9 * np.abs(ref["ref_x"]).max()
 
 
 def test_fixtures_exist():
