@@ -155,6 +155,14 @@ int sfmba_create(const sfmba_options* opts, sfmba_handle** out);
 int sfmba_destroy(sfmba_handle* h);
 const char* sfmba_last_error(const sfmba_handle* h);
 
+/* Where the progress text of sfmba_solve goes (options.verbose >= 1: the termination message;
+ * >= 2: one row per iteration with the columns of SciPy's verbose=2 table,
+ * scipy/optimize/_lsq/common.py print_header_nonlinear / print_iteration_nonlinear, which the
+ * reference asks for at bundle_adjustment.py:141).  sink(text, user) receives whole lines; NULL
+ * restores the default, the process's stdout, flushed after every line.  The sink is called on the
+ * thread that called sfmba_solve. */
+int sfmba_set_print(sfmba_handle* h, void (*sink)(const char* text, void* user), void* user);
+
 /* Load one problem: the arrays BundleAdjustment.view2idx() produces
  * (bundle_adjustment.py:94-126) plus the 3x3 intrinsic matrix (row-major; only K[0][0],
  * K[1][1], K[0][2], K[1][2] are used, as cv2.projectPoints does with empty distortion).

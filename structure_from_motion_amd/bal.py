@@ -16,11 +16,12 @@ import bz2
 import numpy as np
 from scipy.sparse import csr_matrix
 
+from .bundle_adjustment import _digest
 from .engine import Engine, TERMINATION_MESSAGES
 
 __all__ = ["read_bal_data", "write_bal_data", "rotate", "project", "fun", "bundle_adjustment_sparsity", "solve"]
 
-_fun_cache = {"key": None, "engine": None, "keep": None}
+_fun_cache = {"key": None, "engine": None}
 
 
 def _numbers(text):
@@ -117,16 +118,15 @@ def _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d):
     ci = np.asarray(camera_indices)
     pi = np.asarray(point_indices)
     uv = np.asarray(points_2d)
-    key = (n_cameras, n_points, ci.__array_interface__["data"][0], ci.size,
-           pi.__array_interface__["data"][0], uv.__array_interface__["data"][0])
+    key = (n_cameras, n_points, _digest(ci), _digest(pi), _digest(uv))     # by content, as in bundle_adjustment.fun
     if _fun_cache["key"] != key:
         if _fun_cache["engine"] is not None:
             _fun_cache["engine"].close()
-        _fun_cache.update(key=None, engine=None, keep=None)
-        eng = Engine(camera_model="bal")
+        _fun_cache.update(key=None, engine=None)
+        eng = Engine(camera_model="bal", schur_mode=1)      # residuals only
         eng.set_problem(np.tile(np.r_[np.zeros(5), -1.0, 1.0, 0.0, 0.0], (n_cameras, 1)),
                         np.zeros((n_points, 3)), ci, pi, uv, None)
-        _fun_cache.update(key=key, engine=eng, keep=(ci, pi, uv))   # keep the arrays alive
+        _fun_cache.update(key=key, engine=eng)
     return _fun_cache["engine"]
 
 

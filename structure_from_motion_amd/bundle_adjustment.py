@@ -11,17 +11,19 @@ There is no CPU fallback: without the shared library or without a GPU these func
 """
 from __future__ import annotations
 
+import hashlib
 import logging
 import time
 
 import numpy as np
-from scipy.sparse import lil_matrix
+import pandas as pd
+from scipy.sparse import csr_matrix
 
 from .engine import Engine, TERMINATION_MESSAGES
 
 __all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment", "solve_arrays", "solve_npz"]
 
-_fun_cache = {"key": None, "engine": None, "keep": None}
+_fun_cache = {"key": None, "engine": None}
 
 
 def project(points, camera_params, K, dist=np.array([])):
@@ -45,21 +47,31 @@ def project(points, camera_params, K, dist=np.array([])):
         return eng.residuals().reshape(n, 2)
 
 
+def _digest(a):
+    """Content key of an index / observation array: shape, dtype and a hash of the bytes."""
+    a = np.ascontiguousarray(a)
+    return (a.shape, a.dtype.str, hashlib.blake2b(a.view(np.uint8).reshape(-1), digest_size=16).digest())
+
+
 def _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d, K):
+    """Engine holding the observations of ``fun``'s arguments.  ``fun`` is called many times with
+    the same index and observation arrays and a new ``params``; the engine of the last call is
+    kept and reused when the arrays have the same CONTENT (hashing 5 M observations costs a few
+    milliseconds, building the problem tens), so editing an array in place between two calls is
+    seen, as it is by the reference's pure function."""
     ci = np.asarray(camera_indices)
     pi = np.asarray(point_indices)
     uv = np.asarray(points_2d)
     Ka = np.asarray(K, dtype=np.float64)
-    key = (n_cameras, n_points, ci.__array_interface__["data"][0], ci.size,
-           pi.__array_interface__["data"][0], uv.__array_interface__["data"][0], Ka.tobytes())
+    key = (n_cameras, n_points, _digest(ci), _digest(pi), _digest(uv), Ka.tobytes())
     if _fun_cache["key"] != key:
         if _fun_cache["engine"] is not None:
             _fun_cache["engine"].close()
-        _fun_cache.update(key=None, engine=None, keep=None)
-        eng = Engine()
+        _fun_cache.update(key=None, engine=None)
+        eng = Engine(schur_mode=1)      # residuals only: no reduced-matrix structure is built
         eng.set_problem(np.tile(np.r_[np.eye(3).ravel(), 0, 0, 1.0], (n_cameras, 1)),
                         np.zeros((n_points, 3)), ci, pi, uv, Ka)
-        _fun_cache.update(key=key, engine=eng, keep=(ci, pi, uv))   # keep the arrays alive
+        _fun_cache.update(key=key, engine=eng)
     return _fun_cache["engine"]
 
 
@@ -84,19 +96,18 @@ def bundle_adjustment_sparsity(n_cameras, n_points, camera_indices, point_indice
     rows of every observation.  The engine does not need it (its block structure is
     implicit); it is produced for callers that still hand it to SciPy.
     """
-    camera_indices = np.asarray(camera_indices)
-    point_indices = np.asarray(point_indices)
-    m = camera_indices.size * 2
-    n = n_cameras * 12 + n_points * 3
-    A = lil_matrix((m, n), dtype=int)
-    i = np.arange(camera_indices.size)
-    for s in range(12):
-        A[2 * i, camera_indices * 12 + s] = 1
-        A[2 * i + 1, camera_indices * 12 + s] = 1
-    for s in range(3):
-        A[2 * i, n_cameras * 12 + point_indices * 3 + s] = 1
-        A[2 * i + 1, n_cameras * 12 + point_indices * 3 + s] = 1
-    return A
+    cam = np.asarray(camera_indices, dtype=np.int64).ravel()
+    pt = np.asarray(point_indices, dtype=np.int64).ravel()
+    n_obs = cam.size
+    # every row holds its camera's 12 columns, then its point's 3: written down as CSR in one go
+    # and converted, instead of 30 fancy-index assignments into a LIL matrix
+    cols = np.empty((n_obs, 15), dtype=np.int64)
+    cols[:, :12] = 12 * cam[:, None] + np.arange(12)
+    cols[:, 12:] = 12 * n_cameras + 3 * pt[:, None] + np.arange(3)
+    cols = np.repeat(cols, 2, axis=0).ravel()
+    A = csr_matrix((np.ones(cols.size, dtype=int), cols, 15 * np.arange(2 * n_obs + 1)),
+                   shape=(2 * n_obs, 12 * n_cameras + 3 * n_points))
+    return A.tolil()
 
 
 class BundleAdjustment:
@@ -143,11 +154,18 @@ class BundleAdjustment:
         corr = self.correspondences
         n_rows = len(corr)
         if n_rows:
-            view_ids = np.array(corr["ViewId"].tolist(), dtype=object).reshape(n_rows, -1)[:, :2]
-            lookup = self.view_idx
-            self.camera_indices = np.array([lookup[v] for v in view_ids.ravel()], dtype=np.int64)
-            self.points_2d = np.array([np.asarray(f[:2], dtype=np.float64)
-                                       for f in corr["FeatureIndex"]]).reshape(2 * n_rows, -1)
+            # both columns hold one 2-element list per row; no Python-level loop over the rows
+            view_ids = np.array(corr["ViewId"].tolist(), dtype=object).reshape(n_rows, -1)[:, :2].ravel()
+            idx = pd.Series(view_ids).map(self.view_idx)
+            if idx.isna().any():
+                raise KeyError(view_ids[int(np.flatnonzero(idx.isna().to_numpy())[0])])
+            self.camera_indices = idx.to_numpy(dtype=np.int64)
+            feats = corr["FeatureIndex"].tolist()
+            try:
+                xy = np.asarray(feats, dtype=np.float64)                    # (rows, >= 2, 2)
+                self.points_2d = np.ascontiguousarray(xy[:, :2]).reshape(2 * n_rows, -1)
+            except ValueError:                                              # ragged rows
+                self.points_2d = np.array([np.asarray(f[k], dtype=np.float64) for f in feats for k in (0, 1)])
             self.point_indices = np.repeat(np.asarray(corr.index), 2)
         else:
             self.camera_indices = np.array([])

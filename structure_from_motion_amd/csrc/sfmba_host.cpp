@@ -210,6 +210,8 @@ struct sfmba_handle {
     std::string err;
     int device = 0;
     hipStream_t stream = nullptr;
+    void (*print_cb)(const char*, void*) = nullptr;   // sink of the iteration table (sfmba_set_print)
+    void* print_user = nullptr;
     bool has_problem = false;
     bool linearized = false;
     double lin_lambda = 0.0;
@@ -761,14 +763,25 @@ double read_lin_scalars(H* h, double* sc) {
     return std::max(sc[SLOT_GMAX_CAM], m);
 }
 
-void print_header() {
-    printf("%s\n", "   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality   ");
+// Progress text goes to the caller's sink when one is set (sfmba_set_print: the Python binding
+// routes it to sys.stdout, where SciPy's verbose=2 table goes), otherwise to stdout, flushed line
+// by line so that it stays in order with whatever the caller prints itself.
+void emit(H* h, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h->print_cb) { h->print_cb(buf, h->print_user); return; }
+    fputs(buf, stdout);
     fflush(stdout);
 }
-void print_row(int it, int nfev, double cost, double red, double step, double opt, bool first) {
-    if (first) printf("%8d     %10d      %13.4e                                 %10.2e    \n", it, nfev, cost, opt);
-    else printf("%8d     %10d      %13.4e    %10.2e     %10.2e     %10.2e    \n", it, nfev, cost, red, step, opt);
-    fflush(stdout);     // rows appear in order with whatever the caller prints itself
+void print_header(H* h) {
+    emit(h, "%s\n", "   Iteration     Total nfev        Cost      Cost reduction    Step norm     Optimality   ");
+}
+void print_row(H* h, int it, int nfev, double cost, double red, double step, double opt, bool first) {
+    if (first) emit(h, "%8d     %10d      %13.4e                                 %10.2e    \n", it, nfev, cost, opt);
+    else emit(h, "%8d     %10d      %13.4e    %10.2e     %10.2e     %10.2e    \n", it, nfev, cost, red, step, opt);
 }
 
 void do_solve(H* h, sfmba_stats* out) {
@@ -803,7 +816,7 @@ void do_solve(H* h, sfmba_stats* out) {
     int status = -1;
     double step_norm = 0.0, actual = 0.0;
     const bool talk = o.verbose >= 2 && o.rank <= 0;
-    if (talk) { print_header(); print_row(0, st.nfev, cost, actual, step_norm, g_norm, true); }
+    if (talk) { print_header(h); print_row(h, 0, st.nfev, cost, actual, step_norm, g_norm, true); }
     int accepted = 0;
     if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
     // Unless every iteration is printed, the gradient norm of a new linearisation is not waited
@@ -859,7 +872,7 @@ void do_solve(H* h, sfmba_stats* out) {
         const bool ft = actual < ftol * cost && rho > 0.25;
         const bool xt = step_norm < xtol * (xtol + x_norm);
         if (o.verbose >= 3 && o.rank <= 0)
-            { printf("  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e\n", it, cost, cost_new, rho, lambda, step_norm); fflush(stdout); }
+            emit(h, "  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e\n", it, cost, cost_new, rho, lambda, step_norm);
         if (rho > 1e-3) {
             h->cur ^= 1;
             ++accepted;
@@ -871,7 +884,7 @@ void do_solve(H* h, sfmba_stats* out) {
             st.njev++;
             lin_pending = !talk;
             if (!lin_pending) g_norm = read_lin_scalars(h, sc);
-            if (talk) print_row(accepted, st.nfev, cost, actual, step_norm, g_norm, false);
+            if (talk) print_row(h, accepted, st.nfev, cost, actual, step_norm, g_norm, false);
             if (ft && xt) status = SFMBA_STATUS_FTOL_XTOL;
             else if (ft) status = SFMBA_STATUS_FTOL;
             else if (xt) status = SFMBA_STATUS_XTOL;
@@ -921,9 +934,8 @@ void do_solve(H* h, sfmba_stats* out) {
                                     "`ftol` termination condition is satisfied.",
                                     "`xtol` termination condition is satisfied.",
                                     "Both `ftol` and `xtol` termination conditions are satisfied."};
-        printf("%s\nFunction evaluations %d, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n",
-               msg[status], st.nfev, st.initial_cost, st.final_cost, st.optimality);
-        fflush(stdout);
+        emit(h, "%s\nFunction evaluations %d, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n",
+             msg[status], st.nfev, st.initial_cost, st.final_cost, st.optimality);
     }
     if (out) *out = st;
 }
@@ -1669,6 +1681,13 @@ int sfmba_destroy(sfmba_handle* h) {
     if (!h) return SFMBA_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(h->device);
     delete h;
+    return SFMBA_OK;
+}
+
+int sfmba_set_print(sfmba_handle* h, void (*sink)(const char* text, void* user), void* user) {
+    if (!h) return SFMBA_ERR_INVALID_ARGUMENT;
+    h->print_cb = sink;
+    h->print_user = user;
     return SFMBA_OK;
 }
 

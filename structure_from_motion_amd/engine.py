@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -16,7 +17,7 @@ _LIB_PATH = os.environ.get("SFMBA_LIBRARY") or os.path.join(os.path.dirname(os.p
 
 # every symbol include/sfmba.h declares
 EXPORTS = (
-    "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error",
+    "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_set_print",
     "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
     "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_triangulate", "sfmba_point_errors",
     "sfmba_linearize", "sfmba_get_blocks",
@@ -40,6 +41,15 @@ TERMINATION_MESSAGES = {   # scipy/optimize/_lsq/least_squares.py:18-25
     3: "`xtol` termination condition is satisfied.",
     4: "Both `ftol` and `xtol` termination conditions are satisfied.",
 }
+
+
+PRINT_SINK = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+
+
+@PRINT_SINK
+def _print_to_sys_stdout(text, _user):
+    # the iteration table goes where SciPy's print() would put it: the current sys.stdout
+    sys.stdout.write(text.decode("utf-8", "replace"))
 
 
 class Options(C.Structure):
@@ -104,6 +114,7 @@ def load_library(path=None):
     lib.sfmba_destroy.argtypes = [vp]
     lib.sfmba_last_error.argtypes = [vp]
     lib.sfmba_last_error.restype = C.c_char_p
+    lib.sfmba_set_print.argtypes = [vp, PRINT_SINK, vp]
     lib.sfmba_set_problem.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp, dp, ip, ip, dp, dp]
     lib.sfmba_set_params.argtypes = [vp, dp, dp]
     lib.sfmba_reset_params.argtypes = [vp]
@@ -178,6 +189,7 @@ class Engine:
             self._h = C.c_void_p()
             raise EngineError(rc, {-6: "no usable GPU (libsfmba needs a gfx950 device)"}.get(rc, "sfmba_create failed"))
         self.n_cameras = self.n_points = self.n_obs = 0
+        self._lib.sfmba_set_print(self._h, _print_to_sys_stdout, None)
 
     # -- plumbing
     def _check(self, rc):

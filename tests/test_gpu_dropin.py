@@ -50,7 +50,15 @@ def test_optimize_matches_reference_contract(tmp_path, monkeypatch, capsys, capl
     # side effects: npz dump, size print, three log lines
     with np.load(tmp_path / "optimize_data.npz") as z:
         assert sorted(z.files) == ["camera_indices", "camera_params", "point_indices", "points_2d", "points_3d"]
-    assert capsys.readouterr().out.startswith("72 360\n")
+    out = capsys.readouterr().out
+    assert out.startswith("72 360\n")
+    # the verbose=2 table of the least_squares call (bundle_adjustment.py:141) arrives on sys.stdout,
+    # after the sizes, one row per accepted iteration, then the termination message
+    lines = out.split("\n")
+    assert lines[1].split() == ["Iteration", "Total", "nfev", "Cost", "Cost", "reduction", "Step", "norm", "Optimality"]
+    rows = [l for l in lines[2:] if l.strip() and l.split()[0].isdigit()]
+    assert [int(r.split()[0]) for r in rows] == list(range(b.result["accepted"] + 1))
+    assert "termination condition is satisfied" in out and out.index("Iteration") < out.index("termination")
     msgs = [r.getMessage() for r in caplog.records]
     assert "Number of views processed: 6." in msgs and "Number of 3D points processed: 120." in msgs
     assert any(m.startswith("Optimized 120 in ") for m in msgs)
@@ -151,3 +159,14 @@ def test_incremental_ring_of_47_views_solved_after_every_added_view():
     assert checked == 3
     # 46 successive adjustments later the structure has not drifted away from the truth
     assert np.abs(pts - full["true_points_3d"]).max() < 0.2
+
+
+def test_fun_sees_arrays_edited_in_place():
+    # the reference's fun is pure: the same array objects with new contents are a new problem
+    p = syn.make_problem(5, 60, 200, seed=11, window=5)
+    x0, args = o.pack(p)
+    f1 = ba.fun(x0, *args)
+    p["points_2d"][7] += 3.0                       # same object, same address
+    p["camera_indices"][0] = (p["camera_indices"][0] + 1) % 5
+    f2 = ba.fun(x0, *args)
+    assert np.abs(f2 - o.fun(x0, *args)).max() <= 1e-9 and np.abs(f2 - f1).max() > 1.0
