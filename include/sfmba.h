@@ -226,6 +226,20 @@ int sfmba_reprojection_errors(sfmba_handle* h, double* mean_error, int64_t* n_ob
 int sfmba_triangulate(sfmba_handle* h, int64_t n, const double* P1, const double* P2,
                       const double* x1, const double* x2, double* X, double* err1, double* err2);
 
+/* sfmba_triangulate for callers that cannot allocate device memory (tight per-image-pair loops,
+ * harnesses that forbid hipMalloc/hipFree, which also synchronise the device).  It has no
+ * counterpart in the reference.  Same arguments, same kernel and bit-identical results; the
+ * device staging sfmba_triangulate allocates and frees per call lives in a fixed array inside the
+ * library's code object instead (72 bytes per correspondence, 4.5 MiB on every GPU the library
+ * runs on, resolved per device in sfmba_create).  At most SFMBA_TRIANGULATE_NOALLOC_MAX
+ * correspondences per call: more returns SFMBA_ERR_INVALID_ARGUMENT and a message naming the
+ * limit.  The call makes no hipMalloc / hipFree.  All handles on one GPU share that GPU's array:
+ * calls that overlap in time on the same GPU (from several threads or handles) race and must be
+ * serialised by the caller. */
+#define SFMBA_TRIANGULATE_NOALLOC_MAX 65536
+int sfmba_triangulate_noalloc(sfmba_handle* h, int64_t n, const double* P1, const double* P2,
+                              const double* x1, const double* x2, double* X, double* err1, double* err2);
+
 /* Reprojection errors of n given points in one view with projection matrix P (3x4, row-major):
  * calculate_reprojection_error (utils.py:337-352) for a whole array, as the filters of
  * store_3Dpoints_to_views (utils.py:279-315) and reproject_view (view.py:103-119) use it. */

@@ -200,6 +200,40 @@ struct LocalGroup {
     }
 };
 
+// ---------------------------------------------------------------------------------- scratch
+// Device memory of sfmba_triangulate_noalloc: the staging that sfmba_triangulate allocates per
+// call (pixel coordinates in, points and errors out), here a fixed array in the code object of
+// the library.  Every GPU the library runs on holds its own copy at its own address until the
+// process ends; `scratch` itself is only a host-side stand-in for the symbol, the address on a
+// device comes from hipGetSymbolAddress with that device current (scratch_ptr below) and is what
+// copies and kernels are given.
+constexpr int64_t kNoallocMax = SFMBA_TRIANGULATE_NOALLOC_MAX;
+constexpr size_t kScrX1 = 0;                                   // [max] double2
+constexpr size_t kScrX2 = kScrX1 + 16 * (size_t)kNoallocMax;   // [max] double2
+constexpr size_t kScrX = kScrX2 + 16 * (size_t)kNoallocMax;    // [max][3] double
+constexpr size_t kScrErr = kScrX + 24 * (size_t)kNoallocMax;   // [2][max] double
+constexpr size_t kScrBytes = kScrErr + 16 * (size_t)kNoallocMax;
+static __device__ __align__(256) unsigned char scratch[kScrBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of the scratch array on `device`, which must be the current device; resolved once.
+hipError_t scratch_ptr(int device, unsigned char** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_PAIRS, F_COMM, F_COUNT };
 
 }  // namespace
@@ -212,6 +246,7 @@ struct sfmba_handle {
     hipStream_t stream = nullptr;
     void (*print_cb)(const char*, void*) = nullptr;   // sink of the iteration table (sfmba_set_print)
     void* print_user = nullptr;
+    unsigned char* scratch = nullptr;     // this device's address of the library's scratch array
     bool has_problem = false;
     bool linearized = false;
     double lin_lambda = 0.0;
@@ -1667,6 +1702,8 @@ int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
         delete h;
         return SFMBA_ERR_HIP;
     }
+    // this device's copy of the scratch array of sfmba_triangulate_noalloc (once per device)
+    if (scratch_ptr(dev, &h->scratch) != hipSuccess) { delete h; return SFMBA_ERR_HIP; }
     if (hipHostMalloc((void**)&h->pcg_host, 2 * sizeof(PcgState), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&h->pcg_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->pcg_ev[1], hipEventDisableTiming) != hipSuccess) {
@@ -1844,6 +1881,34 @@ int sfmba_triangulate(sfmba_handle* h, int64_t n, const double* P1, const double
         HIP_TRY(hipMemcpyAsync(X, dX.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (err1) HIP_TRY(hipMemcpyAsync(err1, de.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (err2) HIP_TRY(hipMemcpyAsync(err2, de.p + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    });
+}
+
+int sfmba_triangulate_noalloc(sfmba_handle* h, int64_t n, const double* P1, const double* P2,
+                              const double* x1, const double* x2, double* X, double* err1, double* err2) {
+    return guarded(h, [&] {
+        if (n < 0 || !P1 || !P2 || (n > 0 && (!x1 || !x2 || !X)))
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_triangulate_noalloc: bad arguments");
+        if (n > kNoallocMax)
+            fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_triangulate_noalloc: %lld correspondences exceed the limit of %lld "
+                 "(SFMBA_TRIANGULATE_NOALLOC_MAX); use sfmba_triangulate", (long long)n, (long long)kNoallocMax);
+        if (n == 0) return;
+        HIP_TRY(hipSetDevice(h->device));
+        unsigned char* base = h->scratch;      // resolved for this device in sfmba_create
+        double2* d1 = reinterpret_cast<double2*>(base + kScrX1);
+        double2* d2 = reinterpret_cast<double2*>(base + kScrX2);
+        double* dX = reinterpret_cast<double*>(base + kScrX);
+        double* de = reinterpret_cast<double*>(base + kScrErr);
+        // (every word the kernel reads or the copies below return is written first in this call:
+        // nothing of an earlier call's contents is used, nothing has to start at zero)
+        HIP_TRY(hipMemcpyAsync(d1, x1, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d2, x2, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+        launch_triangulate(P1, P2, (int)n, d1, d2, dX, de, de + kNoallocMax, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(X, dX, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (err1) HIP_TRY(hipMemcpyAsync(err1, de, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (err2) HIP_TRY(hipMemcpyAsync(err2, de + kNoallocMax, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     });
 }

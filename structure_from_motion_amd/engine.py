@@ -19,7 +19,7 @@ _LIB_PATH = os.environ.get("SFMBA_LIBRARY") or os.path.join(os.path.dirname(os.p
 EXPORTS = (
     "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_set_print",
     "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
-    "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_triangulate", "sfmba_point_errors",
+    "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_triangulate", "sfmba_triangulate_noalloc", "sfmba_point_errors",
     "sfmba_linearize", "sfmba_get_blocks",
     "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_precondition", "sfmba_solve_step",
     "sfmba_comm_unique_id", "sfmba_comm_init",
@@ -29,6 +29,7 @@ EXPORTS = (
 SOLVER_AUTO, SOLVER_PCG, SOLVER_DENSE = 0, 1, 2
 SCHUR_AUTO, SCHUR_IMPLICIT, SCHUR_EXPLICIT = 0, 1, 2
 CAMERA_PINHOLE, CAMERA_BAL = 0, 1
+TRIANGULATE_NOALLOC_MAX = 65536     # SFMBA_TRIANGULATE_NOALLOC_MAX of include/sfmba.h
 # per camera model: numbers per camera in camera_params, tangent numbers per camera
 CAMERA_SHAPES = {CAMERA_PINHOLE: (12, 6), CAMERA_BAL: (9, 9)}
 CAMERA_NAMES = {"pinhole": CAMERA_PINHOLE, "bal": CAMERA_BAL}
@@ -124,6 +125,7 @@ def load_library(path=None):
     lib.sfmba_get_params.argtypes = [vp, dp, dp]
     lib.sfmba_reprojection_errors.argtypes = [vp, dp, ip]
     lib.sfmba_triangulate.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
+    lib.sfmba_triangulate_noalloc.argtypes = [vp, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
     lib.sfmba_point_errors.argtypes = [vp, C.c_int64, dp, dp, dp, dp]
     lib.sfmba_linearize.argtypes = [vp, C.c_double]
     lib.sfmba_get_blocks.argtypes = [vp, dp, dp, dp, dp]
@@ -278,16 +280,19 @@ class Engine:
         self._check(self._lib.sfmba_reprojection_errors(self._h, _dp(mean), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return mean, cnt
 
-    def triangulate(self, P1, P2, x1, x2):
+    def triangulate(self, P1, P2, x1, x2, noalloc=False):
         """Batched two-view linear triangulation: (X n x 3, err1, err2) for 3x4 projection matrices
-        P1, P2 and n x 2 pixel coordinates x1, x2 (see sfmba_triangulate)."""
+        P1, P2 and n x 2 pixel coordinates x1, x2 (see sfmba_triangulate).  `noalloc` takes the
+        entry point that stages through the library's fixed device array instead of allocating
+        (at most TRIANGULATE_NOALLOC_MAX correspondences per call)."""
         P1 = _f64(P1).reshape(3, 4); P2 = _f64(P2).reshape(3, 4)
         x1 = _f64(x1).reshape(-1, 2); x2 = _f64(x2).reshape(-1, 2)
         n = x1.shape[0]
         if x2.shape[0] != n:
             raise ValueError("x1 and x2 must hold the same number of points")
         X = np.empty((n, 3)); e1 = np.empty(n); e2 = np.empty(n)
-        self._check(self._lib.sfmba_triangulate(self._h, n, _dp(P1), _dp(P2), _dp(x1), _dp(x2), _dp(X), _dp(e1), _dp(e2)))
+        call = self._lib.sfmba_triangulate_noalloc if noalloc else self._lib.sfmba_triangulate
+        self._check(call(self._h, n, _dp(P1), _dp(P2), _dp(x1), _dp(x2), _dp(X), _dp(e1), _dp(e2)))
         return X, e1, e2
 
     def point_errors(self, P, X, x):
