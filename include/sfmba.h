@@ -98,6 +98,11 @@ typedef struct sfmba_options {
      * directions of the whole problem, on which S vanishes up to the damping).  Cameras without
      * observations take no part in it and do not move. */
     int32_t pcg_coarse;
+    /* Where sfmba_set_problem builds the structure of the problem (orderings, chunks, observation
+     * pair lists, block pattern): 0 = on the GPU (sorts and scans; milliseconds), 1 = on host
+     * threads (the first implementation, kept as the layout the GPU path is tested against; both
+     * produce the same arrays, so solves are bit-identical). */
+    int32_t setup_mode;
 } sfmba_options;
 
 /* Camera models.  D = tangent numbers per camera (width of a Jacobian block and of every
@@ -175,6 +180,17 @@ int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int6
                       const double* camera_params, const double* points_3d,
                       const int64_t* camera_indices, const int64_t* point_indices,
                       const double* points_2d, const double* K);
+
+/* sfmba_set_problem for callers whose observations already live in device memory (a pipeline that
+ * keeps correspondences on the GPU): camera_indices, point_indices (int64) and points_2d
+ * (n_obs x 2 doubles) are DEVICE pointers on the handle's GPU in the same layout; camera_params,
+ * points_3d and K stay host pointers (they are small).  The arrays are only read, and only until
+ * the call returns.  No counterpart in the reference, whose arrays are NumPy arrays
+ * (bundle_adjustment.py:117-122). */
+int sfmba_set_problem_device(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
+                             const double* camera_params, const double* points_3d,
+                             const int64_t* camera_indices_dev, const int64_t* point_indices_dev,
+                             const double* points_2d_dev, const double* K);
 
 /* Overwrite the current parameter estimate without re-sending the observations (used to
  * re-run a solve from the same start, and to evaluate fun() at another x). */
@@ -268,6 +284,14 @@ int sfmba_precondition(sfmba_handle* h, const double* r, double* z, int32_t* coa
 /* Solve the damped normal equations for the step at the current linearisation:
  * step_cam n_cameras x 6, step_pt n_points x 3; *pcg_iters receives the iteration count. */
 int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t* pcg_iters);
+
+/* One of the integer arrays sfmba_set_problem derived from the index arrays, by name: the
+ * point-major order (pt_ptr, pm_cam, pm_pt, pm_orig, new2old), the camera-major order (cm_pt,
+ * chunk_cam, chunk_beg, cam_chunk_ptr), wtile_beg, and for the explicit reduced matrix ublk_r,
+ * ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg, pair_a, pair_b,
+ * pair_p, bsr_ptr, bsr_col, bsr_diag.  *count receives the length; out may be NULL to ask for it.
+ * Lets the tests compare the two set-up paths (options.setup_mode) array by array. */
+int sfmba_get_structure(sfmba_handle* h, const char* name, int32_t* out, int64_t capacity, int64_t* count);
 
 /* ---- multi-GPU: one handle (one process) per GPU, RCCL over xGMI ---- */
 

@@ -21,31 +21,11 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/sfmba.h"
-#include "sfmba_internal.h"
+#include "sfmba_handle.h"
 
 using namespace sfmba;
 
 namespace {
-
-// ---------------------------------------------------------------------------------- errors
-struct HipError { hipError_t e; const char* what; };
-#define HIP_TRY(expr)                                              \
-    do {                                                           \
-        hipError_t e_ = (expr);                                    \
-        if (e_ != hipSuccess) throw HipError{e_, #expr};           \
-    } while (0)
-
-struct ApiError { int code; std::string msg; };
-
-[[noreturn]] void fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    throw ApiError{code, buf};
-}
 
 // ---------------------------------------------------------------------------------- RCCL
 // Resolved at run time so that a single-GPU process never needs the library.
@@ -148,58 +128,6 @@ void polar3(const double* R, double* Q) {
     }
 }
 
-// ---------------------------------------------------------------------------------- buffers
-template <class T>
-struct DBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    void alloc(size_t count) {
-        release();
-        n = count;
-        if (count) HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
-    }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
-    void upload(const std::vector<T>& h, hipStream_t st) {
-        if (h.size() != n) alloc(h.size());
-        if (n) HIP_TRY(hipMemcpyAsync(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
-    }
-    void zero(hipStream_t st) { if (n) HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), st)); }
-    ~DBuf() { release(); }
-    DBuf() = default;
-    DBuf(const DBuf&) = delete;
-    DBuf& operator=(const DBuf&) = delete;
-};
-
-// In-process group: the handles of several host threads of one process (one per GPU, or
-// several on one GPU) all-reduce through device copies instead of RCCL.
-struct LocalGroup {
-    int n = 0;
-    std::mutex m;
-    std::condition_variable cv;
-    int arrived = 0;
-    long generation = 0;
-    int next_rank_check = 0;
-    std::vector<double*> bufs;
-    std::vector<size_t> counts;
-    std::vector<int> devices;
-    bool failed = false;      // written by rank 0 between two barriers, read by the others after the second
-    bool aborted = false;     // a member failed outside a collective: nobody waits for it any more
-    // Returns false when the group was aborted (before or while waiting).
-    bool barrier() {
-        std::unique_lock<std::mutex> lk(m);
-        if (aborted) return false;
-        const long gen = generation;
-        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen || aborted; });
-        return !aborted;
-    }
-    void abort() {
-        std::lock_guard<std::mutex> lk(m);
-        aborted = true;
-        cv.notify_all();
-    }
-};
-
 // ---------------------------------------------------------------------------------- scratch
 // Device memory of sfmba_triangulate_noalloc: the staging that sfmba_triangulate allocates per
 // call (pixel coordinates in, points and errors out), here a fixed array in the code object of
@@ -234,127 +162,10 @@ hipError_t scratch_ptr(int device, unsigned char** out) {
     return hipSuccess;
 }
 
-enum Family { F_LIN = 0, F_DAMP, F_SPMV_PM, F_SPMV_CM, F_PCGVEC, F_BACK, F_COST, F_DENSE, F_SCHUR, F_BSR, F_PAIRS, F_COMM, F_COUNT };
 
 }  // namespace
 
-// ---------------------------------------------------------------------------------- handle
-struct sfmba_handle {
-    sfmba_options opt;
-    std::string err;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    void (*print_cb)(const char*, void*) = nullptr;   // sink of the iteration table (sfmba_set_print)
-    void* print_user = nullptr;
-    unsigned char* scratch = nullptr;     // this device's address of the library's scratch array
-    bool has_problem = false;
-    bool linearized = false;
-    double lin_lambda = 0.0;
-    double damped_lambda = -1.0;   // damping for which Vinv and s0 are current
-    bool have_v = false;           // V_p and g_p of the current linearisation are in memory
-    bool fuse_cm = false;          // explicit matrix: one camera-major pass instead of two when the damping is known
-    double cm_lambda = -1.0;       // damping for which the one-pass camera sums (UG, T) are current; < 0: two passes
-
-    // global shape and this partition
-    int64_t n_cam = 0, n_pts_all = 0, n_obs_all = 0;
-    int64_t pt_lo = 0, pt_hi = 0;          // owned point range
-    int n_pts = 0, n_obs = 0, n_chunks = 0, nb_cam = 0;
-    int chunk = kChunk;
-    int model = MODEL_PINHOLE;             // camera model of the loaded problem
-    int cd = 6, cv = 27, cw = 6;           // per camera: tangent numbers, packed upper + gradient, 16-byte words
-    std::vector<int> new2old;              // internal (renumbered) local point id -> caller's local point id
-
-    // device memory
-    DBuf<int> pt_ptr, pm_cam, pm_pt, pm_orig, cm_pt, chunk_cam, chunk_beg, cam_chunk_ptr;
-    DBuf<double2> pm_uv, cm_uv;
-    DBuf<double2> cams[2], cams0;
-    DBuf<double4> X[2], X0;
-    DBuf<double4> pm_seed;
-    DBuf<int> wtile_beg;
-    int n_wtiles = 0;
-    DBuf<double> pm_rv, cm_sx, cm_sy, cm_siz;
-    DBuf<double> V, gp, Vinv, chunk_part, UG, T, Minv, rhs;
-    DBuf<double4> s, s0;
-    DBuf<double> px, pr, pz, pp[2], pq, qS;
-    DBuf<PcgState> pcg;
-    PcgState* pcg_host = nullptr;          // pinned, [2]
-    hipEvent_t pcg_ev[2] = {nullptr, nullptr};
-    DBuf<double> dot_part, scal_part, scalars;
-    DBuf<double> tmp_a, tmp_b;             // API staging (residuals, Jacobian blocks, vectors)
-    // explicit block-sparse Schur complement
-    bool explicit_schur = false;
-    int n_ublk = 0, n_pchunks = 0, nnzb = 0, nb_bsr = 0, dot_off = 0;
-    int64_t n_pairs = 0;
-    DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg;
-    DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
-    DBuf<double> pair_part, Bsum, Sfull;
-    // single-launch PCG on the scaled system
-    bool fused_pcg = false, fused_armed = false, fused_refused = false;
-    int fused_blocks = 0;
-    int64_t fused_solves = 0, fused_fallbacks = 0;
-    DBuf<double> Shat, Fscale, bhat, fvec;    // fvec: generation records, p, xh
-    DBuf<double2> fdots;
-    bool trace_pcg = false;
-    FusedPcg fused{};
-    // two-level preconditioner of the launch-per-iteration PCG on the explicit matrix
-    bool coarse_built = false;   // cluster structure and buffers present
-    bool coarse_forced = false;  // asked for: in use from the first solve on
-    bool coarse_on = false;      // the next solve uses it
-    bool coarse_failed = false;  // a solve with it did not converge: not used again in this sfmba_solve
-    bool coarse_valid = false;   // E^-1 belongs to the matrix in Sfull
-    int64_t coarse_solves = 0;
-    int coarse_from = 0;         // switched on after a solve of this many iterations
-    DBuf<int> cl_ptr, cam_cl, cpair_i, cpair_j, cpair_cptr, cchunk_beg, cpair_blk, cpair_row;
-    DBuf<double> cZ, cE[2], cscale, crc, cpart;
-    Coarse coarse{};
-    // dense Cholesky solver
-    bool use_dense = false;      // dense Cholesky asked for
-    bool dense_allowed = false;  // small enough for the dense fallback
-    int dense_n = 0;
-    DBuf<double> denseA, denseLinv, denseWork;
-    DBuf<int> dense_fail;
-    int dense_fallbacks = 0;
-    int cur = 0;                           // index of the current parameter buffers
-    Dev dev{};
-
-    // communication
-    ncclComm_t comm = nullptr;
-    LocalGroup* group = nullptr;
-    bool has_comm() const { return comm != nullptr || group != nullptr; }
-
-    // timing
-    bool profile = false;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    struct Span { int fam; hipEvent_t a, b; };
-    std::vector<Span> spans;
-    double fam_ms[F_COUNT] = {};
-    int64_t fam_n[F_COUNT] = {};
-
-    ~sfmba_handle() {
-        for (auto e : ev_pool) (void)hipEventDestroy(e);
-        for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
-        if (pcg_host) (void)hipHostFree(pcg_host);
-        if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
-
 namespace {
-
-using H = sfmba_handle;
-
-// Phase times of sfmba_set_problem on stderr when SFMBA_TRACE_SETUP is set.
-struct SetupTrace {
-    bool on = getenv("SFMBA_TRACE_SETUP") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char* what) {
-        if (!on) return;
-        const auto n = std::chrono::steady_clock::now();
-        fprintf(stderr, "  setup %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
-        t = n;
-    }
-};
 
 void refresh_dev(H* h) {
     Dev& d = h->dev;
@@ -1040,20 +851,21 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d) {
     HIP_TRY(hipSetDevice(h->device));
     std::vector<double2> cams;
     pack_cameras(h, camera_params, cams);
-    std::vector<double4> X((size_t)h->n_pts);
-    for (int p = 0; p < h->n_pts; ++p) {
-        const double* x = points_3d + 3 * (h->pt_lo + h->new2old[p]);
-        X[p] = make_double4(x[0], x[1], x[2], 0.0);
-    }
+    // the owned points as the caller numbers them, permuted into the internal order on the device
+    const size_t np = (size_t)h->n_pts;
+    h->in_pts.alloc(3 * np);
     h->cur = 0;
     h->cams[0].upload(cams, h->stream);
     h->cams[1].alloc(cams.size());
-    h->X[0].upload(X, h->stream);
-    h->X[1].upload(X, h->stream);       // points without observations are never rewritten
+    h->X[0].alloc(np); h->X[1].alloc(np); h->X0.alloc(np);
     h->cams0.alloc(cams.size());
-    h->X0.alloc(X.size());
+    if (np) {
+        HIP_TRY(hipMemcpyAsync(h->in_pts.p, points_3d + 3 * h->pt_lo, 3 * np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_points_in(h->in_pts.p, h->new2old_dev.p, (int)np, h->X[0].p, h->stream);
+        HIP_TRY(hipMemcpyAsync(h->X[1].p, h->X[0].p, np * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));   // points without observations are never rewritten
+        HIP_TRY(hipMemcpyAsync(h->X0.p, h->X[0].p, np * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
+    }
     HIP_TRY(hipMemcpyAsync(h->cams0.p, h->cams[0].p, cams.size() * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-    if (!X.empty()) HIP_TRY(hipMemcpyAsync(h->X0.p, h->X[0].p, X.size() * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->linearized = false;
     refresh_dev(h);
@@ -1096,19 +908,17 @@ struct KeySet {
 // rank, so that all ranks agree on the layout) plus every diagonal; per upper block the list of
 // this partition's observation pairs; the full block-CSR pattern and where each upper block and
 // its transpose land in it.
-void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, const int64_t* pt_idx,
-                           const std::vector<int64_t>& pre, const std::vector<int>& pt_ptr,
-                           const std::vector<int>& pm_cam, const std::vector<int>& pm2cm) {
-    const int n_cam = (int)h->n_cam, np = h->n_pts, no = h->n_obs;
-    SetupTrace tr;
+}  // namespace
+
+// What the options and the environment ask of the reduced system.
+SchurPlan sfmba::plan_schur(H* h) {
     int mode = h->opt.schur_mode;
     if (const char* e = getenv("SFMBA_SCHUR_MODE")) mode = atoi(e);
     int lin = h->opt.linear_solver;
     if (const char* e = getenv("SFMBA_LINEAR_SOLVER")) lin = atoi(e);
     const int dense_max = h->opt.dense_max_dim > 0 ? h->opt.dense_max_dim : 1536;
     const bool want_dense = lin == SFMBA_SOLVER_DENSE;
-    const int64_t n_red = (int64_t)h->cd * n_cam;       // unknowns of the reduced system
-    const size_t nn = (size_t)h->cd * h->cd;
+    const int64_t n_red = (int64_t)h->cd * h->n_cam;       // unknowns of the reduced system
     h->dense_allowed = lin == SFMBA_SOLVER_AUTO && n_red <= dense_max;
     if (n_red > 16384 && lin == SFMBA_SOLVER_DENSE)
         fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)n_red);
@@ -1117,6 +927,19 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->explicit_schur = false;
     h->n_ublk = h->n_pchunks = h->nnzb = 0;
     h->n_pairs = 0;
+    return {mode, want_dense};
+}
+
+namespace {
+
+void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, const int64_t* pt_idx,
+                           const std::vector<int64_t>& pre, const std::vector<int>& pt_ptr,
+                           const std::vector<int>& pm_cam, const std::vector<int>& pm2cm) {
+    const int n_cam = (int)h->n_cam, np = h->n_pts, no = h->n_obs;
+    SetupTrace tr;
+    const SchurPlan plan = plan_schur(h);
+    const int mode = plan.mode;
+    const bool want_dense = plan.want_dense;
     if (mode == 1) return;
     // pairs of this partition
     int64_t n_pairs = 0;
@@ -1293,13 +1116,31 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     h->pchunk_blk.upload(pchunk_blk, st); h->pchunk_beg.upload(pchunk_beg, st);
     h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
     h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);
-    h->pair_part.alloc((size_t)std::max<size_t>(pchunk_blk.size(), 1) * nn);
+    h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
+    h->bsr_ptr_host = bsr_ptr; h->bsr_col_host = bsr_col;
+    finish_schur_setup(h, want_dense);
+    tr.lap("schur: upload + solver set-up");
+}
+
+// Everything of the explicit reduced system that depends on its structure only through the counts
+// (n_ublk, n_pchunks, nnzb, n_pairs) and the block pattern on the host: value arrays, the
+// single-launch PCG, the coarse space, the dense solver.  Shared by both set-up paths.
+}  // namespace
+
+void sfmba::finish_schur_setup(H* h, bool want_dense) {
+    const int n_cam = (int)h->n_cam;
+    const int n_ublk = h->n_ublk, nnzb = h->nnzb;
+    const size_t nn = (size_t)h->cd * h->cd;
+    const int64_t n_red = (int64_t)h->cd * n_cam;
+    const std::vector<int>& bsr_ptr = h->bsr_ptr_host;
+    const std::vector<int>& bsr_col = h->bsr_col_host;
+    SetupTrace tr;
+    hipStream_t st = h->stream;
+    h->pair_part.alloc((size_t)std::max<size_t>((size_t)h->n_pchunks, 1) * nn);
     h->Bsum.alloc((size_t)n_ublk * nn + (size_t)n_cam * h->cv);     // + the per-camera sums T_c, one collective
     h->Sfull.alloc((size_t)nnzb * nn);
     h->Bsum.zero(st); h->Sfull.zero(st);
     HIP_TRY(hipStreamSynchronize(st));
-    tr.lap("schur: upload");
-    h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
     h->explicit_schur = true;
     // one camera-major pass per linearisation instead of two (k_lin_sdiag_cm): measured for the
     // 6-number camera; the 9-number camera would carry 72 running sums per lane
@@ -1435,9 +1276,11 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     }
 }
 
-void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const double* camera_params,
-                    const double* points_3d, const int64_t* cam_idx, const int64_t* pt_idx,
-                    const double* points_2d, const double* K) {
+namespace {
+
+// Argument checks and the shape of the problem, common to both set-up paths.
+void begin_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const void* camera_params, const void* points_3d,
+                   const void* cam_idx, const void* pt_idx, const void* points_2d, const double* K) {
     if (n_cam <= 0 || n_pts <= 0 || n_obs < 0) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes must be positive");
     const int model = h->opt.camera_model;
     if (model != SFMBA_CAMERA_PINHOLE && model != SFMBA_CAMERA_BAL)
@@ -1448,6 +1291,21 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem: sizes exceed 32-bit indexing");
     HIP_TRY(hipSetDevice(h->device));
     h->has_problem = false;
+    h->n_cam = n_cam; h->n_pts_all = n_pts; h->n_obs_all = n_obs;
+    h->model = model == SFMBA_CAMERA_BAL ? MODEL_BAL : MODEL_PINHOLE;
+    h->cd = cam_dim(h->model); h->cv = cam_sums(h->model); h->cw = cam_words(h->model);
+    h->dev.model = h->model;
+    h->dev.K = K ? Intr{K[0], K[4], K[2], K[5]} : Intr{1.0, 1.0, 0.0, 0.0};
+    if (const char* e = getenv("SFMBA_CHUNK")) { int v = atoi(e); if (v >= 64) h->chunk = v; }
+    h->nb_cam = (int)((n_cam + kBlock - 1) / kBlock);
+}
+
+void alloc_work_buffers(H* h);
+
+// The structure of the problem built on host threads (counting sorts, pair lists), then uploaded.
+// Kept as the reference layout the device path (sfmba_setup.hip) must reproduce.
+void host_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const double* points_2d) {
+    const int64_t n_cam = h->n_cam, n_pts = h->n_pts_all, n_obs = h->n_obs_all;
     SetupTrace tr;
     // The sorts below run on several host threads.  Every pass gives thread t a range of the KEYS
     // (points or cameras); each thread scans all observations in order and handles those whose key
@@ -1475,12 +1333,6 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
             fail(SFMBA_ERR_INDEX_RANGE, "index %lld is out of bounds for axis 0 with size %lld", (long long)pt_idx[i], (long long)n_pts);
         }
     }
-    h->n_cam = n_cam; h->n_pts_all = n_pts; h->n_obs_all = n_obs;
-    h->model = model == SFMBA_CAMERA_BAL ? MODEL_BAL : MODEL_PINHOLE;
-    h->cd = cam_dim(h->model); h->cv = cam_sums(h->model); h->cw = cam_words(h->model);
-    h->dev.model = h->model;
-    h->dev.K = K ? Intr{K[0], K[4], K[2], K[5]} : Intr{1.0, 1.0, 0.0, 0.0};
-
     // observations per point, then the owned point range: contiguous, equal observation share
     std::vector<int> cnt((size_t)n_pts + 1, 0);
     run_threads([&](int t) {
@@ -1568,7 +1420,6 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         }
     });
     // chunks: pieces of at most `chunk` observations of one camera
-    if (const char* e = getenv("SFMBA_CHUNK")) { int v = atoi(e); if (v >= 64) h->chunk = v; }
     std::vector<int> chunk_cam, chunk_beg, cam_chunk_ptr((size_t)n_cam + 1, 0);
     for (int64_t c = 0; c < n_cam; ++c) {
         cam_chunk_ptr[c] = (int)chunk_cam.size();
@@ -1577,8 +1428,6 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     cam_chunk_ptr[n_cam] = (int)chunk_cam.size();
     chunk_beg.push_back(no);
     h->n_chunks = (int)chunk_cam.size();
-    h->nb_cam = (int)((n_cam + kBlock - 1) / kBlock);
-    if ((np + kBlock - 1) / kBlock > kMaxScalBlocks) fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many points for one GPU");
 
     tr.lap("camera-major sort + chunks");
     hipStream_t st = h->stream;
@@ -1586,7 +1435,6 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
     h->pm_orig.upload(pm_orig, st); h->pm_uv.upload(pm_uv, st);
     h->cm_pt.upload(cm_pt, st); h->cm_uv.upload(cm_uv, st);
     h->chunk_cam.upload(chunk_cam, st); h->chunk_beg.upload(chunk_beg, st); h->cam_chunk_ptr.upload(cam_chunk_ptr, st);
-    for (DBuf<double>* b : {&h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
     {   // wave tiles of the point-major order: whole points, <= 64 observations (or one long point)
         std::vector<int> wt;
         int beg = 0;
@@ -1600,9 +1448,24 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         h->n_wtiles = (int)wt.size();
         wt.push_back(no);
         h->wtile_beg.upload(wt, st);
-        if ((h->n_wtiles + 3) / 4 > kMaxScalBlocks || (no + kBlock - 1) / kBlock > kMaxScalBlocks)
-            fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many observations for one GPU");
     }
+    h->new2old_dev.upload(h->new2old, st);
+    h->device_built = false;
+    tr.lap("uploads");
+    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm2cm);
+    HIP_TRY(hipStreamSynchronize(st));      // the uploads read host vectors that end here
+    tr.lap("schur structure (total)");
+}
+
+// Arrays whose sizes follow from the counts of the structure (either path).
+void alloc_work_buffers(H* h) {
+    const int np = h->n_pts, no = h->n_obs;
+    const int64_t n_cam = h->n_cam;
+    hipStream_t st = h->stream;
+    if ((np + kBlock - 1) / kBlock > kMaxScalBlocks) fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many points for one GPU");
+    if ((h->n_wtiles + 3) / 4 > kMaxScalBlocks || (no + kBlock - 1) / kBlock > kMaxScalBlocks)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "partition has too many observations for one GPU");
+    for (DBuf<double>* b : {&h->cm_sx, &h->cm_sy, &h->cm_siz}) b->alloc((size_t)no);
     h->V.alloc((size_t)np * 6); h->gp.alloc((size_t)np * 4); h->Vinv.alloc((size_t)np * 6);
     h->V.zero(st); h->gp.zero(st);      // points without observations are never written
     h->s.alloc((size_t)np); h->s0.alloc((size_t)np);
@@ -1620,17 +1483,59 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         h->dot_off = std::max(h->nb_cam, pcg_spmv_blocks(t));       // p'q partials, then r'z partials
         h->pcg.alloc(2); h->dot_part.alloc((size_t)h->dot_off + pcg_update_blocks(t));
     }
-    tr.lap("uploads + allocations");
-    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm2cm);
-    tr.lap("schur structure (total)");
     if (h->explicit_schur) { h->pm_seed.release(); h->pm_rv.release(); }     // only the matrix-free product reads them
     else { h->pm_seed.alloc((size_t)no); h->pm_rv.alloc((size_t)no); }
     h->scal_part.alloc((size_t)SLOT_COUNT * kMaxScalBlocks); h->scalars.alloc(SLOT_COUNT);
     h->scal_part.zero(st); h->scalars.zero(st); h->chunk_part.zero(st);
     h->tmp_b.alloc((size_t)std::max<int64_t>(64, n_cam * (int64_t)(cd * cd)));
     HIP_TRY(hipStreamSynchronize(st));
+}
+
+// How the structure is built: on the GPU unless the host path is asked for (options.setup_mode or
+// SFMBA_SETUP=host; it is the layout the device path is tested against).
+bool use_device_setup(const H* h) {
+    if (const char* e = getenv("SFMBA_SETUP")) return strcmp(e, "host") != 0;
+    return h->opt.setup_mode != 1;
+}
+
+void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const double* camera_params,
+                    const double* points_3d, const int64_t* cam_idx, const int64_t* pt_idx,
+                    const double* points_2d, const double* K) {
+    begin_problem(h, n_cam, n_pts, n_obs, camera_params, points_3d, cam_idx, pt_idx, points_2d, K);
+    SetupTrace tr;
+    if (use_device_setup(h)) {
+        hipStream_t st = h->stream;
+        h->in_cam.alloc((size_t)n_obs); h->in_pt.alloc((size_t)n_obs); h->in_uv.alloc((size_t)n_obs);
+        if (n_obs) {
+            HIP_TRY(hipMemcpyAsync(h->in_cam.p, cam_idx, (size_t)n_obs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->in_pt.p, pt_idx, (size_t)n_obs * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->in_uv.p, points_2d, (size_t)n_obs * sizeof(double2), hipMemcpyHostToDevice, st));
+        }
+        tr.lap("upload of the caller's arrays");
+        device_setup(h, h->in_cam.p, h->in_pt.p, h->in_uv.p);
+        tr.lap("structure on the device");
+    } else {
+        host_setup(h, cam_idx, pt_idx, points_2d);
+    }
+    alloc_work_buffers(h);
+    tr.lap("work buffers");
     do_set_params(h, camera_params, points_3d);
     tr.lap("parameters");
+    h->has_problem = true;
+}
+
+// The same with the observations already in device memory (reference layout: int64 indices,
+// n_obs x 2 doubles); cameras and points are small and still come from the host.
+void do_set_problem_device(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const double* camera_params,
+                           const double* points_3d, const int64_t* cam_idx_dev, const int64_t* pt_idx_dev,
+                           const double* points_2d_dev, const double* K) {
+    begin_problem(h, n_cam, n_pts, n_obs, camera_params, points_3d, cam_idx_dev, pt_idx_dev, points_2d_dev, K);
+    SetupTrace tr;
+    device_setup(h, cam_idx_dev, pt_idx_dev, reinterpret_cast<const double2*>(points_2d_dev));
+    tr.lap("structure on the device");
+    alloc_work_buffers(h);
+    do_set_params(h, camera_params, points_3d);
+    tr.lap("work buffers + parameters");
     h->has_problem = true;
 }
 
@@ -1660,6 +1565,14 @@ int guarded(sfmba_handle* h, F&& f) {
     return code;
 }
 
+// The host copy of the point permutation (diagnostic entry points): the device path leaves it
+// on the GPU until somebody asks.
+void fetch_new2old(H* h) {
+    if (h->new2old.size() == (size_t)h->n_pts) return;
+    h->new2old.resize((size_t)h->n_pts);
+    if (h->n_pts) HIP_TRY(hipMemcpy(h->new2old.data(), h->new2old_dev.p, (size_t)h->n_pts * sizeof(int), hipMemcpyDeviceToHost));
+}
+
 void need_problem(H* h, const char* who) {
     if (!h->has_problem) fail(SFMBA_ERR_INVALID_ARGUMENT, "%s: no problem set", who);
     HIP_TRY(hipSetDevice(h->device));
@@ -1684,6 +1597,7 @@ void sfmba_default_options(sfmba_options* o) {
     o->pcg_mode = 0; o->pcg_blocks = 0;
     o->camera_model = SFMBA_CAMERA_PINHOLE;
     o->pcg_coarse = 0;
+    o->setup_mode = 0;
 }
 
 int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
@@ -1736,6 +1650,15 @@ int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int6
                       const double* points_2d, const double* K) {
     return guarded(h, [&] {
         do_set_problem(h, n_cameras, n_points, n_obs, camera_params, points_3d, camera_indices, point_indices, points_2d, K);
+    });
+}
+
+int sfmba_set_problem_device(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
+                             const double* camera_params, const double* points_3d,
+                             const int64_t* camera_indices_dev, const int64_t* point_indices_dev,
+                             const double* points_2d_dev, const double* K) {
+    return guarded(h, [&] {
+        do_set_problem_device(h, n_cameras, n_points, n_obs, camera_params, points_3d, camera_indices_dev, point_indices_dev, points_2d_dev, K);
     });
 }
 
@@ -1817,27 +1740,18 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
             HIP_TRY(hipMemcpyAsync(camera_params, h->cams[h->cur].p, (size_t)h->n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         }
         if (points_3d) {
-            std::vector<double4> X((size_t)h->n_pts);
-            if (h->n_pts) HIP_TRY(hipMemcpyAsync(X.data(), h->X[h->cur].p, X.size() * sizeof(double4), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            // back into the caller's numbering on the device; with several ranks every rank returns
+            // all points: the sum of zero-padded full-length arrays
+            const size_t full = (size_t)h->n_pts_all * 3;
+            if (h->tmp_a.n < full) h->tmp_a.alloc(full);
+            if (h->has_comm()) HIP_TRY(hipMemsetAsync(h->tmp_a.p, 0, full * sizeof(double), h->stream));
+            double* dst = h->tmp_a.p + (h->has_comm() ? 3 * (size_t)h->pt_lo : 0);
+            if (h->n_pts) launch_points_out(h->X[h->cur].p, h->new2old_dev.p, h->n_pts, dst, h->stream);
             if (h->has_comm()) {
-                // every rank returns all points: sum of zero-padded full-length arrays
-                std::vector<double> full((size_t)h->n_pts_all * 3, 0.0);
-                for (int p = 0; p < h->n_pts; ++p) {
-                    double* o = full.data() + 3 * (h->pt_lo + h->new2old[p]);
-                    o[0] = X[p].x; o[1] = X[p].y; o[2] = X[p].z;
-                }
-                DBuf<double> d;
-                d.alloc(full.size());
-                HIP_TRY(hipMemcpyAsync(d.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-                allreduce(h, d.p, full.size());
-                HIP_TRY(hipMemcpyAsync(points_3d, d.p, full.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-                HIP_TRY(hipStreamSynchronize(h->stream));
-            } else {
-                for (int p = 0; p < h->n_pts; ++p) {
-                    double* o = points_3d + 3 * (h->pt_lo + h->new2old[p]);
-                    o[0] = X[p].x; o[1] = X[p].y; o[2] = X[p].z;
-                }
+                allreduce(h, h->tmp_a.p, full);
+                HIP_TRY(hipMemcpyAsync(points_3d, h->tmp_a.p, full * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            } else if (h->n_pts) {
+                HIP_TRY(hipMemcpyAsync(points_3d + 3 * h->pt_lo, dst, 3 * (size_t)h->n_pts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             }
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1944,6 +1858,7 @@ int sfmba_linearize(sfmba_handle* h, double lambda) {
 int sfmba_get_blocks(sfmba_handle* h, double* U, double* g_cam, double* V, double* g_pt) {
     return guarded(h, [&] {
         need_linearized(h, "sfmba_get_blocks");
+        fetch_new2old(h);
         // (inside a solve the camera sums are formed in one pass and U_c is not kept on its own)
         if (h->cm_lambda >= 0.0 && (U || g_cam)) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_get_blocks: call sfmba_linearize first");
         // (nor are V_p and g_p stored when the points were damped in the linearisation pass)
@@ -2035,6 +1950,7 @@ int sfmba_precondition(sfmba_handle* h, const double* r, double* z, int32_t* coa
 int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t* pcg_iters) {
     return guarded(h, [&] {
         need_linearized(h, "sfmba_solve_step");
+        fetch_new2old(h);
         int it = phase_linear_solve(h, h->lin_lambda);
         if (pcg_iters) *pcg_iters = it;
         DBuf<double> dp;
@@ -2049,6 +1965,31 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
         if (step_pt)
             for (int p = 0; p < h->n_pts; ++p)
                 for (int i = 0; i < 3; ++i) step_pt[3 * (h->pt_lo + h->new2old[p]) + i] = hdp[3 * (size_t)p + i];
+    });
+}
+
+int sfmba_get_structure(sfmba_handle* h, const char* name, int32_t* out, int64_t capacity, int64_t* count) {
+    return guarded(h, [&] {
+        need_problem(h, "sfmba_get_structure");
+        if (!name || !count) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_get_structure: null argument");
+        struct Entry { const char* name; const DBuf<int>* buf; };
+        const Entry table[] = {
+            {"pt_ptr", &h->pt_ptr}, {"pm_cam", &h->pm_cam}, {"pm_pt", &h->pm_pt}, {"pm_orig", &h->pm_orig}, {"cm_pt", &h->cm_pt},
+            {"chunk_cam", &h->chunk_cam}, {"chunk_beg", &h->chunk_beg}, {"cam_chunk_ptr", &h->cam_chunk_ptr},
+            {"wtile_beg", &h->wtile_beg}, {"new2old", &h->new2old_dev},
+            {"ublk_r", &h->ublk_r}, {"ublk_c", &h->ublk_c}, {"ublk_chunk_ptr", &h->ublk_chunk_ptr}, {"ublk_pos", &h->ublk_pos},
+            {"ublk_pos_t", &h->ublk_pos_t}, {"ublk_diag", &h->ublk_diag}, {"pchunk_blk", &h->pchunk_blk}, {"pchunk_beg", &h->pchunk_beg},
+            {"pair_a", &h->pair_a}, {"pair_b", &h->pair_b}, {"pair_p", &h->pair_p},
+            {"bsr_ptr", &h->bsr_ptr}, {"bsr_col", &h->bsr_col}, {"bsr_diag", &h->bsr_diag}};
+        const DBuf<int>* b = nullptr;
+        for (const Entry& e : table) if (strcmp(e.name, name) == 0) b = e.buf;
+        if (!b) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_get_structure: no array named %s", name);
+        const bool schur = strncmp(name, "ublk", 4) == 0 || strncmp(name, "pchunk", 6) == 0 || strncmp(name, "pair", 4) == 0 || strncmp(name, "bsr", 3) == 0;
+        const int64_t n = schur && !h->explicit_schur ? 0 : (int64_t)b->n;
+        *count = n;
+        if (!out) return;
+        if (capacity < n) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_get_structure: %s holds %lld entries", name, (long long)n);
+        if (n) HIP_TRY(hipMemcpy(out, b->p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     });
 }
 
@@ -2074,6 +2015,7 @@ int sfmba_comm_init(sfmba_handle* h, const void* unique_id128) {
         memcpy(&id, unique_id128, sizeof id);
         ncclResult_t r = g_rccl.CommInitRank(&h->comm, h->opt.nranks, id, h->opt.rank);
         if (r != ncclSuccess) { h->comm = nullptr; fail(SFMBA_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+        h->comm_destroy = g_rccl.CommDestroy;
     });
 }
 

@@ -202,6 +202,9 @@ void launch_gmax_cam(const Dev& d, hipStream_t st);
 void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st);   // [n_cam][2] = (sum of errors, count)
 int scal_blocks_pt(const Dev& d);
 void launch_vec_add(double* a, const double* b, size_t n, hipStream_t st);
+// caller's point numbering <-> internal order: X[p] = in[new2old[p]] and back (n x 3 doubles)
+void launch_points_in(const double* in, const int* new2old, int n, double4* X, hipStream_t st);
+void launch_points_out(const double4* X, const int* new2old, int n, double* out, hipStream_t st);
 int blocks_cam(const Dev& d);
 // sfmba_schur.hip
 int bsr_blocks(const Dev& d);

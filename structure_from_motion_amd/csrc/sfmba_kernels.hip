@@ -867,6 +867,29 @@ void launch_vec_add(double* a, const double* b, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, a, b, n);
 }
 
+// Points between the caller's numbering (n x 3 doubles) and the internal order (double4 records).
+__global__ __launch_bounds__(kBlock) void k_points_in(const double* __restrict__ in, const int* __restrict__ new2old, int n,
+                                                      double4* __restrict__ X) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const double* x = in + 3 * (size_t)new2old[p];
+    X[p] = make_double4(x[0], x[1], x[2], 0.0);
+}
+__global__ __launch_bounds__(kBlock) void k_points_out(const double4* __restrict__ X, const int* __restrict__ new2old, int n,
+                                                       double* __restrict__ out) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const double4 x = X[p];
+    double* o = out + 3 * (size_t)new2old[p];
+    o[0] = x.x; o[1] = x.y; o[2] = x.z;
+}
+void launch_points_in(const double* in, const int* new2old, int n, double4* X, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_points_in, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, in, new2old, n, X);
+}
+void launch_points_out(const double4* X, const int* new2old, int n, double* out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_points_out, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, X, new2old, n, out);
+}
+
 // ------------------------------------------------------------------------------------------
 int scal_blocks_pt(const Dev& d) { return cdiv(d.n_pts, kBlock); }
 static int blocks_wtile(const Dev& d) { return cdiv(d.n_wtiles, kBlock / 64); }

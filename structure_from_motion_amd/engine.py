@@ -18,10 +18,10 @@ _LIB_PATH = os.environ.get("SFMBA_LIBRARY") or os.path.join(os.path.dirname(os.p
 # every symbol include/sfmba.h declares
 EXPORTS = (
     "sfmba_default_options", "sfmba_create", "sfmba_destroy", "sfmba_last_error", "sfmba_set_print",
-    "sfmba_set_problem", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
+    "sfmba_set_problem", "sfmba_set_problem_device", "sfmba_set_params", "sfmba_reset_params", "sfmba_residuals", "sfmba_jacobian_blocks",
     "sfmba_solve", "sfmba_get_params", "sfmba_reprojection_errors", "sfmba_triangulate", "sfmba_triangulate_noalloc", "sfmba_point_errors",
     "sfmba_linearize", "sfmba_get_blocks",
-    "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_precondition", "sfmba_solve_step",
+    "sfmba_schur_matvec", "sfmba_get_reduced", "sfmba_precondition", "sfmba_solve_step", "sfmba_get_structure",
     "sfmba_comm_unique_id", "sfmba_comm_init",
     "sfmba_local_group_create", "sfmba_local_group_destroy", "sfmba_comm_init_local",
 )
@@ -62,6 +62,7 @@ class Options(C.Structure):
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
         ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32), ("camera_model", C.c_int32), ("pcg_coarse", C.c_int32),
+        ("setup_mode", C.c_int32),
     ]
 
 
@@ -117,6 +118,7 @@ def load_library(path=None):
     lib.sfmba_last_error.restype = C.c_char_p
     lib.sfmba_set_print.argtypes = [vp, PRINT_SINK, vp]
     lib.sfmba_set_problem.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp, dp, ip, ip, dp, dp]
+    lib.sfmba_set_problem_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, dp, dp, vp, vp, vp, dp]
     lib.sfmba_set_params.argtypes = [vp, dp, dp]
     lib.sfmba_reset_params.argtypes = [vp]
     lib.sfmba_residuals.argtypes = [vp, dp]
@@ -133,6 +135,7 @@ def load_library(path=None):
     lib.sfmba_get_reduced.argtypes = [vp, dp, dp]
     lib.sfmba_precondition.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
     lib.sfmba_solve_step.argtypes = [vp, dp, dp, C.POINTER(C.c_int32)]
+    lib.sfmba_get_structure.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]
     lib.sfmba_comm_unique_id.argtypes = [vp]
     lib.sfmba_comm_init.argtypes = [vp, vp]
     lib.sfmba_local_group_create.argtypes = [C.c_int32, C.POINTER(vp)]
@@ -241,6 +244,31 @@ class Engine:
             self._h, cp.shape[0], pts.shape[0], ci.size, _dp(cp), _dp(pts),
             ci.ctypes.data_as(ipp), pi.ctypes.data_as(ipp), _dp(uv), _dp(K)))
 
+    def set_problem_device(self, camera_params, points_3d, camera_indices, point_indices, points_2d, K):
+        """set_problem with the observations already on this engine's GPU: camera_indices,
+        point_indices (int64, n_obs) and points_2d (float64, n_obs x 2) are contiguous device
+        tensors (anything with data_ptr(), shape and dtype, e.g. torch.Tensor); the rest as in
+        set_problem."""
+        cp, pts = _f64(camera_params), _f64(points_3d)
+        K = _f64(K) if K is not None else None
+        if cp.ndim != 2 or cp.shape[1] != self.cam_params:
+            raise ValueError(f"camera_params must be (n_cameras, {self.cam_params})")
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points_3d must be (n_points, 3)")
+        if K is None and self.options.camera_model == CAMERA_PINHOLE or (K is not None and K.shape != (3, 3)):
+            raise ValueError("K must be 3x3")
+        n = int(camera_indices.shape[0])
+        if tuple(point_indices.shape) != (n,) or tuple(points_2d.shape) != (n, 2) or len(camera_indices.shape) != 1:
+            raise ValueError("camera_indices, point_indices (n_obs,) and points_2d (n_obs, 2) disagree")
+        for t, want in ((camera_indices, "int64"), (point_indices, "int64"), (points_2d, "float64")):
+            if want not in str(t.dtype) or not t.is_contiguous():
+                raise ValueError(f"device arrays must be contiguous {want}")
+        self.n_cameras, self.n_points, self.n_obs = cp.shape[0], pts.shape[0], n
+        self._check(self._lib.sfmba_set_problem_device(
+            self._h, cp.shape[0], pts.shape[0], n, _dp(cp), _dp(pts),
+            C.c_void_p(camera_indices.data_ptr()), C.c_void_p(point_indices.data_ptr()),
+            C.c_void_p(points_2d.data_ptr()), _dp(K)))
+
     def set_params(self, camera_params, points_3d):
         cp, pts = _f64(camera_params), _f64(points_3d)
         if cp.shape != (self.n_cameras, self.cam_params) or pts.shape != (self.n_points, 3):
@@ -340,6 +368,14 @@ class Engine:
         it = C.c_int32(0)
         self._check(self._lib.sfmba_solve_step(self._h, _dp(dc), _dp(dp), C.byref(it)))
         return dc, dp, it.value
+
+    def structure(self, name):
+        """One of the integer arrays the set-up derived from the index arrays (sfmba_get_structure)."""
+        n = C.c_int64(0)
+        self._check(self._lib.sfmba_get_structure(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.int32)
+        self._check(self._lib.sfmba_get_structure(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return out
 
     # -- multi-GPU
     @staticmethod
