@@ -90,6 +90,10 @@ def camera_rotations(camera_params):
     c = (Q[:, 0, 0] + Q[:, 1, 1] + Q[:, 2, 2] - 1.0) * 0.5
     snap = (s < 1e-5) & (c > 0)
     Q[snap] = np.eye(3)
+    # within 1e-5 of a half turn cv2.Rodrigues takes the axis from the diagonal and the angle from
+    # the trace: the vector -> matrix round trip is then not the identity (few cameras: slow path)
+    for n in np.flatnonzero((s < 1e-5) & ~(c > 0)):
+        Q[n] = rodrigues_vector_to_matrix(rodrigues_matrix_to_vector(Q[n]))
     return Q
 
 

@@ -98,6 +98,44 @@ def edge_problem():
             "points_2d": uv, "K": p["K"], "n_cameras": 5, "n_points": X.shape[0], "n_obs": ci.size}
 
 
+def near_pi_problem():
+    """Cameras whose rotation lies within 1e-5 rad of a half turn: cv2.Rodrigues then rebuilds the
+    rotation vector from the diagonal of the matrix (the branch sin < 1e-5, cos <= 0).  The fixture's
+    residuals come from the literal per-observation loop (o.project_loop), not from the vectorised
+    oracle, so that both the oracle's fast path and the engine are checked against it."""
+    p = syn.make_problem(4, 40, 120, seed=13, window=4)
+    cp = p["camera_params"].copy()
+    k = np.array([0.6, 0.0, 0.8])
+    cp[1, :9] = o.rodrigues_vector_to_matrix(k * (np.pi - 2e-6)).ravel()
+    cp[2, :9] = np.diag([-1.0, 1.0, -1.0]).ravel()                       # exactly a half turn about y
+    k = np.array([-0.36, 0.48, 0.8])
+    cp[3, :9] = (o.rodrigues_vector_to_matrix(k * (np.pi - 7e-6)) * (1 + 1e-4)).ravel()   # and not quite orthonormal
+    p["camera_params"] = cp
+    return p
+
+
+def record_loop(name, prob):
+    """Inputs and f0 from the literal loop of bundle_adjustment.py:22-30."""
+    out = {k: prob[k] for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d", "K")}
+    proj = o.project_loop(prob["points_3d"][prob["point_indices"]], prob["camera_params"][prob["camera_indices"]], prob["K"])
+    out["f0"] = (proj - prob["points_2d"]).ravel()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: n_obs={prob['camera_indices'].size} cost0={0.5 * out['f0'] @ out['f0']:.6e} (literal loop)")
+
+
+def record_full_size(name, prob):
+    """A full-size configuration: the problem itself is regenerated from its seed by the test;
+    stored are SciPy's result with the reference's keyword arguments and a thinned f0 (every 97th
+    entry plus the cost), which pin the generator and the residuals without a megabyte of data."""
+    x0, args = o.pack(prob)
+    f0 = o.fun(x0, *args)
+    r = o.solve_reference(prob)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), shape=np.array([prob["n_cameras"], prob["n_points"], prob["n_obs"]]),
+                        f0_thin=f0[::97], ref_initial_cost=r["initial_cost"], ref_cost=r["cost"], ref_status=r["status"],
+                        ref_nfev=r["nfev"], ref_njev=r["njev"], ref_optimality=r["optimality"], ref_seconds=r["seconds"])
+    print(f"{name}: cost0={r['initial_cost']:.9e} ref={r['cost']:.9e} status={r['status']} nfev={r['nfev']} in {r['seconds']:.1f} s")
+
+
 def nonortho_problem():
     """Rotation blocks that are not orthonormal (noise 1e-3, one scaled by 1.7, one exactly the
     identity): pins the polar-projection semantics of the 12-number camera."""
@@ -187,6 +225,12 @@ def main():
     if "--bal-only" in sys.argv:
         bal_fixtures()
         return
+    if "--fountain-only" in sys.argv:
+        record_full_size("full_fountain", syn.make_shape("fountain", seed=0))
+        return
+    if "--near-pi-only" in sys.argv:
+        record_loop("nearpi_4_40_120", near_pi_problem())
+        return
     if "--triangulation-only" in sys.argv:
         record_triangulation("tri_two_view_400", 400, seed=21, noise_px=0.5)
         record_triangulation("tri_exact_64", 64, seed=22, noise_px=0.0)
@@ -197,6 +241,7 @@ def main():
     record("nonortho_6_60_200", nonortho_problem())
     record("edge_5_13", edge_problem(), jac=False, solve=False, tight=False)   # FD across Z == 0 is meaningless
     record("ladybug_49_7776_31843", syn.make_shape("ladybug", seed=0), jac=False, tight_nfev=60)
+    record_loop("nearpi_4_40_120", near_pi_problem())
     record_triangulation("tri_two_view_400", 400, seed=21, noise_px=0.5)
     record_triangulation("tri_exact_64", 64, seed=22, noise_px=0.0)
     bal_fixtures()

@@ -11,6 +11,7 @@ There is no CPU fallback: without the shared library or without a GPU these func
 """
 from __future__ import annotations
 
+import atexit
 import hashlib
 import logging
 import time
@@ -21,9 +22,36 @@ from scipy.sparse import csr_matrix
 
 from .engine import Engine, TERMINATION_MESSAGES
 
-__all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment", "solve_arrays", "solve_npz"]
+__all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment", "solve_arrays", "solve_npz", "release_engines"]
 
 _fun_cache = {"key": None, "engine": None}
+# Engines of optimize(), one per set of options, kept between calls: the reference's driver makes a
+# new BundleAdjustment after every image (main.py:115-116), and a handle that already holds device
+# memory loads the next, slightly larger, problem in milliseconds instead of allocating afresh.
+_solve_engines = {}
+
+
+def _solve_engine(opts):
+    key = tuple(sorted(opts.items()))
+    eng = _solve_engines.get(key)
+    if eng is None:
+        if len(_solve_engines) >= 4:                  # a handful of option sets at most
+            _solve_engines.pop(next(iter(_solve_engines))).close()
+        eng = _solve_engines[key] = Engine(**opts)
+    return eng
+
+
+def release_engines():
+    """Free the device memory held between calls by fun() and optimize()."""
+    for eng in list(_solve_engines.values()):
+        eng.close()
+    _solve_engines.clear()
+    if _fun_cache["engine"] is not None:
+        _fun_cache["engine"].close()
+    _fun_cache.update(key=None, engine=None)
+
+
+atexit.register(release_engines)
 
 
 def project(points, camera_params, K, dist=np.array([])):
@@ -191,16 +219,16 @@ class BundleAdjustment:
         if self.max_nfev:
             opts["max_nfev"] = int(self.max_nfev)
         opts.update(self.engine_options)
-        with Engine(**opts) as eng:
-            eng.set_problem(self.camera_params, self.points_3d, self.camera_indices,
-                            self.point_indices, self.points_2d, self.K)
-            t0 = time.time()
-            stats = eng.solve()
-            t1 = time.time()
-            poses, points_3d = eng.get_params()
-            # per-view mean reprojection error at the optimum (what main.py:123 prints per view
-            # through ImageView.reproject_view), computed where the data already is
-            self.reprojection_error, self.reprojection_count = eng.reprojection_errors()
+        eng = _solve_engine(opts)
+        eng.set_problem(self.camera_params, self.points_3d, self.camera_indices,
+                        self.point_indices, self.points_2d, self.K)
+        t0 = time.time()
+        stats = eng.solve()
+        t1 = time.time()
+        poses, points_3d = eng.get_params()
+        # per-view mean reprojection error at the optimum (what main.py:123 prints per view
+        # through ImageView.reproject_view), computed where the data already is
+        self.reprojection_error, self.reprojection_count = eng.reprojection_errors()
         logging.info(f"Optimized {self.n_points} in {t1-t0} seconds.")
         self.result = stats.as_dict()
         self.result["message"] = TERMINATION_MESSAGES[stats.status]

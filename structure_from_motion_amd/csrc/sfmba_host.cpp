@@ -125,6 +125,22 @@ void polar3(const double* R, double* Q) {
     double c = (Q[0] + Q[4] + Q[8] - 1.0) * 0.5;
     if (s < 1e-5 && c > 0) {
         for (int i = 0; i < 9; ++i) Q[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    } else if (s < 1e-5) {
+        // Within 1e-5 of a half turn cv2.Rodrigues takes the axis from the diagonal of the matrix
+        // (signs from the first row, one more sign rule for the smallest component) and the angle
+        // acos(c) from the trace; cv2.projectPoints then rotates by exactly that vector.
+        const double cc = std::min(1.0, std::max(-1.0, c));
+        const double theta = std::acos(cc);
+        double vx = std::sqrt(std::max((Q[0] + 1.0) * 0.5, 0.0));
+        double vy = std::sqrt(std::max((Q[4] + 1.0) * 0.5, 0.0)) * (Q[1] < 0 ? -1.0 : 1.0);
+        double vz = std::sqrt(std::max((Q[8] + 1.0) * 0.5, 0.0)) * (Q[2] < 0 ? -1.0 : 1.0);
+        if (std::fabs(vx) < std::fabs(vy) && std::fabs(vx) < std::fabs(vz) && ((Q[5] > 0) != (vy * vz > 0))) vz = -vz;
+        const double n = std::sqrt(vx * vx + vy * vy + vz * vz);
+        const double k[3] = {vx / n, vy / n, vz / n};
+        const double ct = std::cos(theta), st = std::sin(theta), v1 = 1.0 - ct;
+        Q[0] = ct + v1 * k[0] * k[0];         Q[1] = v1 * k[0] * k[1] - st * k[2];  Q[2] = v1 * k[0] * k[2] + st * k[1];
+        Q[3] = v1 * k[1] * k[0] + st * k[2];  Q[4] = ct + v1 * k[1] * k[1];         Q[5] = v1 * k[1] * k[2] - st * k[0];
+        Q[6] = v1 * k[2] * k[0] - st * k[1];  Q[7] = v1 * k[2] * k[1] + st * k[0];  Q[8] = ct + v1 * k[2] * k[2];
     }
 }
 

@@ -140,3 +140,58 @@ def test_two_level_preconditioner_beyond_the_single_launch_solver():
     assert st.status == ref.status and st.iterations == ref.iterations
     assert abs(st.final_cost - ref.final_cost) <= 1e-6 * ref.final_cost
     assert st.pcg_iterations < 0.5 * ref.pcg_iterations
+
+
+# ---- the reference's own recorded run: 11 views / 34 093 points / 68 186 observations
+# (logs/2021-05-10T21_43_23_sfm_runtime_log.log:379-381), at full size against SciPy's result on
+# the same seeded problem (tests/golden/full_fountain.npz, made by oracle/gen_golden.py --fountain-only)
+def test_fountain_shape_at_full_size_against_scipy():
+    import os
+    from helpers import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "full_fountain.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    p = syn.make_shape("fountain", seed=0)
+    assert [p["n_cameras"], p["n_points"], p["n_obs"]] == g["shape"].tolist() == [11, 34093, 68186]
+    with _engine(p) as eng:
+        f = eng.residuals()
+        st = eng.solve()
+        poses, pts = eng.get_params()
+    thin = g["f0_thin"]
+    assert np.abs(f[::97] - thin).max() <= 1e-10 * np.abs(thin).max()          # same problem, same residuals
+    assert abs(st.initial_cost - float(g["ref_initial_cost"])) <= 1e-10 * float(g["ref_initial_cost"])
+    assert st.status in (1, 2, 3, 4)
+    assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)                   # reference tolerances: not worse than SciPy
+    assert poses.shape == (11, 12) and pts.shape == (34093, 3)
+
+
+# ---- the largest configuration: 13 682 cameras / 4 456 117 points / 28 987 644 observations
+@pytest.fixture(scope="module")
+def final_shape():
+    return syn.make_shape("final", seed=0)
+
+
+def test_final_shape_at_full_size(final_shape):
+    p = final_shape
+    assert (p["n_cameras"], p["n_points"], p["n_obs"]) == syn.SHAPES["final"]
+    out = {}
+    with _engine(p) as eng:
+        f = eng.residuals()
+        st = eng.solve()
+        eng.reset_params()
+        st2 = eng.solve()
+        eng.set_params(p["true_camera_params"], p["true_points_3d"])
+        ft = eng.residuals()
+    # two kernels, one cost; residual RMS at the truth is the injected noise
+    assert abs(0.5 * float(f @ f) - st.initial_cost) <= 1e-11 * st.initial_cost
+    assert abs(float(np.sqrt(np.mean(ft * ft))) - 0.5) < 0.001
+    # converged to the noise floor, bitwise repeatable, two-level preconditioner in use
+    n_res = 2 * p["n_obs"]; n_par = 6 * p["n_cameras"] + 3 * p["n_points"]
+    expect = 0.5 * (n_res - n_par) * 0.25
+    assert st.status in (1, 2, 3, 4) and abs(st.final_cost - expect) < 0.01 * expect
+    assert st2.final_cost == st.final_cost and st2.pcg_iterations == st.pcg_iterations
+    assert st.pcg_single_launch == 0 and st.pcg_coarse_solves > 0
+    # block-Jacobi alone reaches the same cost with many more iterations
+    with _engine(p, pcg_coarse=-1) as eng:
+        ref = eng.solve()
+    assert ref.iterations == st.iterations and abs(ref.final_cost - st.final_cost) <= 1e-6 * st.final_cost
+    assert st.pcg_iterations < 0.5 * ref.pcg_iterations

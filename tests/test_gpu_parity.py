@@ -42,6 +42,16 @@ def test_residuals_match_golden(name):
     assert elementwise_rel(f, g["f0"], floor=1.0) <= 1e-10
 
 
+def test_half_turn_rotations_match_the_literal_loop():
+    # rotations within 1e-5 rad of a half turn: cv2.Rodrigues' diagonal branch (axis from the
+    # diagonal, angle acos of the trace), reproduced when the cameras are packed.  Tolerance 1e-8 of
+    # the largest residual: acos near -1 amplifies one ulp of the polar factor by ~1e6.
+    g = load_golden("nearpi_4_40_120")
+    with make_engine(g) as eng:
+        f = eng.residuals()
+    assert np.abs(f - g["f0"]).max() <= 1e-8 * np.abs(g["f0"]).max()
+
+
 def test_fun_dropin_matches_oracle_at_several_points():
     g = load_golden("shuffled_9_200_700")
     x0, args = o.pack(g)

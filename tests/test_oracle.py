@@ -27,6 +27,24 @@ def test_vectorised_projection_equals_reference_loop(name):
     assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
 
 
+def test_half_turn_rotations_follow_the_literal_loop():
+    # fixture made by the per-observation loop: within 1e-5 rad of a half turn cv2.Rodrigues rebuilds
+    # the axis from the diagonal, which moves a camera by up to 1e-6 rad (milli-pixels).  acos near
+    # -1 amplifies one ulp of the polar factor by 1/sin(angle) ~ 1e6, hence 1e-9 and not 1e-12.
+    g = load_golden("nearpi_4_40_120")
+    x0, args = o.pack(g)
+    f = o.fun(x0, *args)
+    assert np.abs(f - g["f0"]).max() <= 1e-9 * np.abs(g["f0"]).max()
+    # and the branch matters: the plain polar factor is milli-pixels away
+    U, _, Vt = np.linalg.svd(g["camera_params"][:, :9].reshape(-1, 3, 3))
+    plain = g["camera_params"].copy()
+    plain[:, :9] = (U @ Vt).reshape(-1, 9)
+    ci, pi = g["camera_indices"], g["point_indices"]
+    Y = np.einsum("nij,nj->ni", (U @ Vt)[ci], g["points_3d"][pi]) + plain[ci, 9:]
+    u = g["K"][0, 0] * Y[:, 0] / Y[:, 2] + g["K"][0, 2] - g["points_2d"][:, 0]
+    assert np.abs(u - g["f0"][0::2]).max() > 1e-4
+
+
 def test_rodrigues_round_trip_and_small_angle_snap():
     rng = np.random.default_rng(0)
     for _ in range(20):
