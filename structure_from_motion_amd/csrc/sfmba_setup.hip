@@ -230,44 +230,47 @@ __global__ __launch_bounds__(kT) void k_tile_jump(const int* __restrict__ jin, i
 // point's observations): a pair of two cameras goes to the upper block (min, max) with the
 // observation of the smaller camera first; two observations of the same camera give two entries
 // (a, b) and (b, a) of that camera's diagonal block.
-__global__ __launch_bounds__(kT) void k_pair_counts(const int* __restrict__ ptr, const int* __restrict__ cam, int n, int skip_lo, int skip_hi,
-                                                    long long* __restrict__ cnt) {
-    const int p = blockIdx.x * kT + threadIdx.x;
-    if (p > n) return;
+// One thread per observation a: its pairs (a, b) with the later observations b of the same point.
+// `pt` gives the point of every observation, `ptr` the observation range of every point; points
+// in [skip_lo, skip_hi) are left out.
+__global__ __launch_bounds__(kT) void k_pair_counts(const int* __restrict__ ptr, const int* __restrict__ pt, const int* __restrict__ cam, int n,
+                                                    int skip_lo, int skip_hi, long long* __restrict__ cnt) {
+    const int a = blockIdx.x * kT + threadIdx.x;
+    if (a > n) return;
     long long c = 0;
-    if (p < n && !(p >= skip_lo && p < skip_hi)) {
-        const int b0 = ptr[p], b1 = ptr[p + 1];
-        const long long k = b1 - b0;
-        c = k * (k - 1) / 2;
-        for (int a = b0; a < b1; ++a)
-            for (int b = a + 1; b < b1; ++b) c += cam[a] == cam[b];
+    if (a < n) {
+        const int p = pt[a];
+        if (!(p >= skip_lo && p < skip_hi)) {
+            const int b1 = ptr[p + 1], ca = cam[a];
+            c = b1 - 1 - a;
+            for (int b = a + 1; b < b1; ++b) c += cam[b] == ca;
+        }
     }
-    cnt[p] = c;
+    cnt[a] = c;
 }
 template <bool kOwned>
-__global__ __launch_bounds__(kT) void k_pair_fill(const int* __restrict__ ptr, const int* __restrict__ cam, int n, int skip_lo, int skip_hi,
-                                                  const long long* __restrict__ off, unsigned long long n_cam,
+__global__ __launch_bounds__(kT) void k_pair_fill(const int* __restrict__ ptr, const int* __restrict__ pt, const int* __restrict__ cam, int n,
+                                                  int skip_lo, int skip_hi, const long long* __restrict__ off, unsigned long long n_cam,
                                                   const int* __restrict__ pm2cm, unsigned long long* __restrict__ keys,
-                                                  int* __restrict__ vals, int seq0, int* __restrict__ ga, int* __restrict__ gb, int* __restrict__ gp) {
-    const int p = blockIdx.x * kT + threadIdx.x;
-    if (p >= n || (p >= skip_lo && p < skip_hi)) return;
-    const int b0 = ptr[p], b1 = ptr[p + 1];
-    long long k = off[p];
-    for (int a = b0; a < b1; ++a) {
-        const int ca = cam[a];
-        for (int b = a + 1; b < b1; ++b) {
-            const int cb = cam[b];
-            const int lo = min(ca, cb), hi = max(ca, cb);
-            const int first = ca <= cb ? a : b, second = ca <= cb ? b : a;
-            const int reps = ca == cb ? 2 : 1;
-            for (int r = 0; r < reps; ++r, ++k) {
-                keys[k] = (unsigned long long)lo * n_cam + (unsigned long long)hi;
-                if (kOwned) {
-                    vals[k] = seq0 + (int)k;
-                    ga[k] = pm2cm[r ? second : first]; gb[k] = pm2cm[r ? first : second]; gp[k] = p;
-                } else {
-                    vals[k] = -1;
-                }
+                                                  int* __restrict__ vals, int* __restrict__ ga, int* __restrict__ gb, int* __restrict__ gp) {
+    const int a = blockIdx.x * kT + threadIdx.x;
+    if (a >= n) return;
+    const int p = pt[a];
+    if (p >= skip_lo && p < skip_hi) return;
+    const int b1 = ptr[p + 1], ca = cam[a];
+    long long k = off[a];
+    for (int b = a + 1; b < b1; ++b) {
+        const int cb = cam[b];
+        const int lo = min(ca, cb), hi = max(ca, cb);
+        const int first = ca <= cb ? a : b, second = ca <= cb ? b : a;
+        const int reps = ca == cb ? 2 : 1;
+        for (int r = 0; r < reps; ++r, ++k) {
+            keys[k] = (unsigned long long)lo * n_cam + (unsigned long long)hi;
+            if (kOwned) {
+                vals[k] = (int)k;
+                ga[k] = pm2cm[r ? second : first]; gb[k] = pm2cm[r ? first : second]; gp[k] = p;
+            } else {
+                vals[k] = -1;
             }
         }
     }
@@ -452,21 +455,21 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const dou
     const SchurPlan plan = plan_schur(h);
     if (plan.mode == 1) { HIP_TRY(hipStreamSynchronize(st)); return; }
     Arena B(h->ws[1]);
-    B.reserve(2 * Arena::pad(8 * ((size_t)np + 2)) + 2 * Arena::pad(8 * ((size_t)P + 2)) + 16 * 256);
-    long long* pcnt = B.get<long long>((size_t)np + 1);
-    long long* poff = B.get<long long>((size_t)np + 1);
-    long long* ocnt = B.get<long long>((size_t)P + 1);
-    long long* ooff = B.get<long long>((size_t)P + 1);
+    B.reserve(2 * Arena::pad(8 * ((size_t)no + 2)) + 2 * Arena::pad(8 * ((size_t)N + 2)) + 16 * 256);
+    long long* pcnt = B.get<long long>((size_t)no + 1);
+    long long* poff = B.get<long long>((size_t)no + 1);
     const bool others = no != N;                       // other ranks' points: only their camera pairs matter
-    hipLaunchKernelGGL(k_pair_counts, dim3(grid_for((size_t)np + 1)), dim3(kT), 0, st, h->pt_ptr.p, h->pm_cam.p, np, 0, 0, pcnt);
-    exclusive_scan(h, pcnt, poff, (size_t)np + 1);
+    long long* ocnt = B.get<long long>(others ? (size_t)N + 1 : 1);
+    long long* ooff = B.get<long long>(others ? (size_t)N + 1 : 1);
+    hipLaunchKernelGGL(k_pair_counts, dim3(grid_for((size_t)no + 1)), dim3(kT), 0, st, h->pt_ptr.p, h->pm_pt.p, h->pm_cam.p, no, 0, 0, pcnt);
+    exclusive_scan(h, pcnt, poff, (size_t)no + 1);
     long long totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&totals[0], poff + np, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&totals[0], poff + no, sizeof(long long), hipMemcpyDeviceToHost, st));
     if (others) {
-        hipLaunchKernelGGL(k_pair_counts, dim3(grid_for((size_t)P + 1)), dim3(kT), 0, st, pre, reinterpret_cast<const int*>(scam), P,
-                           pt_lo, pt_lo + np, ocnt);
-        exclusive_scan(h, ocnt, ooff, (size_t)P + 1);
-        HIP_TRY(hipMemcpyAsync(&totals[1], ooff + P, sizeof(long long), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_pair_counts, dim3(grid_for((size_t)N + 1)), dim3(kT), 0, st, pre, reinterpret_cast<const int*>(spt),
+                           reinterpret_cast<const int*>(scam), N, pt_lo, pt_lo + np, ocnt);
+        exclusive_scan(h, ocnt, ooff, (size_t)N + 1);
+        HIP_TRY(hipMemcpyAsync(&totals[1], ooff + N, sizeof(long long), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     const int64_t n_pairs = totals[0], n_other = totals[1];
@@ -486,11 +489,11 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const dou
     // entries: the diagonal of every camera first (so that every diagonal block exists), this
     // rank's pairs in point order, then the other ranks' pairs
     hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(C)), dim3(kT), 0, st, C, keys[0], vals[0]);
-    hipLaunchKernelGGL((k_pair_fill<true>), dim3(grid_for(np)), dim3(kT), 0, st, h->pt_ptr.p, h->pm_cam.p, np, 0, 0, poff,
-                               (unsigned long long)C, pm2cm, keys[0] + C, vals[0] + C, 0, ga, gb, gp);
-    if (others) hipLaunchKernelGGL((k_pair_fill<false>), dim3(grid_for(P)), dim3(kT), 0, st, pre, reinterpret_cast<const int*>(scam), P, pt_lo,
-                                   pt_lo + np, ooff, (unsigned long long)C, nullptr, keys[0] + C + n_pairs, vals[0] + C + n_pairs, 0,
-                                   nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_pair_fill<true>), dim3(grid_for(no)), dim3(kT), 0, st, h->pt_ptr.p, h->pm_pt.p, h->pm_cam.p, no, 0, 0, poff,
+                       (unsigned long long)C, pm2cm, keys[0] + C, vals[0] + C, ga, gb, gp);
+    if (others) hipLaunchKernelGGL((k_pair_fill<false>), dim3(grid_for(N)), dim3(kT), 0, st, pre, reinterpret_cast<const int*>(spt),
+                                   reinterpret_cast<const int*>(scam), N, pt_lo, pt_lo + np, ooff, (unsigned long long)C, nullptr,
+                                   keys[0] + C + n_pairs, vals[0] + C + n_pairs, nullptr, nullptr, nullptr);
     sort_pairs(h, keys[0], keys[1], vals[0], vals[1], M, bits_for((uint64_t)C * (uint64_t)C));
     // block starts and kept entries -> block index and pair position of every entry
     int* head = vals[0];                                   // (the unsorted values are no longer needed)
