@@ -130,6 +130,8 @@ struct HandleData {
     DBuf<double2> in_uv;
     DBuf<double> in_pts;
     DBuf<unsigned char> ws[12];
+    const int* setup_pm2cm = nullptr;      // point-major -> camera-major position (inside ws[0])
+    hipStream_t copy_stream = nullptr;     // uploads that overlap the set-up kernels
     // block pattern on the host (coarse-space set-up), filled by either set-up path
     std::vector<int> bsr_ptr_host, bsr_col_host;
 
@@ -206,6 +208,7 @@ struct HandleData {
         for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
         if (pcg_host) (void)hipHostFree(pcg_host);
         if (comm && comm_destroy) comm_destroy(comm);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -232,7 +235,10 @@ struct SetupTrace {
 
 // sfmba_setup.hip: the problem structure (orderings, chunks, wave tiles, pair lists, block
 // pattern) built on the GPU from the caller's index arrays already in device memory.
-void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const double2* uv);
+// device_setup needs the two index arrays only; device_place_uv, called after it, puts the image
+// points into both orders.
+void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx);
+void device_place_uv(H* h, const double2* uv);
 
 // sfmba_host.cpp: what the options ask of the reduced system (and the reset of the handle's
 // explicit-matrix state), and everything that follows from the structure once its counts, device

@@ -863,21 +863,24 @@ void pack_cameras(H* h, const double* camera_params, std::vector<double2>& out) 
     }
 }
 
-void do_set_params(H* h, const double* camera_params, const double* points_3d) {
+// `points_on_device`: in_pts already holds ALL points in the caller's numbering (sfmba_set_problem
+// uploaded them beside the set-up kernels); otherwise the owned range is uploaded here.
+void do_set_params(H* h, const double* camera_params, const double* points_3d, bool points_on_device = false) {
     HIP_TRY(hipSetDevice(h->device));
     std::vector<double2> cams;
     pack_cameras(h, camera_params, cams);
     // the owned points as the caller numbers them, permuted into the internal order on the device
     const size_t np = (size_t)h->n_pts;
-    h->in_pts.alloc(3 * np);
+    if (!points_on_device) h->in_pts.alloc(3 * np);
     h->cur = 0;
     h->cams[0].upload(cams, h->stream);
     h->cams[1].alloc(cams.size());
     h->X[0].alloc(np); h->X[1].alloc(np); h->X0.alloc(np);
     h->cams0.alloc(cams.size());
     if (np) {
-        HIP_TRY(hipMemcpyAsync(h->in_pts.p, points_3d + 3 * h->pt_lo, 3 * np * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        launch_points_in(h->in_pts.p, h->new2old_dev.p, (int)np, h->X[0].p, h->stream);
+        if (!points_on_device)
+            HIP_TRY(hipMemcpyAsync(h->in_pts.p, points_3d + 3 * h->pt_lo, 3 * np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        launch_points_in(h->in_pts.p + (points_on_device ? 3 * (size_t)h->pt_lo : 0), h->new2old_dev.p, (int)np, h->X[0].p, h->stream);
         HIP_TRY(hipMemcpyAsync(h->X[1].p, h->X[0].p, np * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));   // points without observations are never rewritten
         HIP_TRY(hipMemcpyAsync(h->X0.p, h->X[0].p, np * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
     }
@@ -1519,23 +1522,46 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
                     const double* points_2d, const double* K) {
     begin_problem(h, n_cam, n_pts, n_obs, camera_params, points_3d, cam_idx, pt_idx, points_2d, K);
     SetupTrace tr;
+    bool points_uploaded = false;      // all of points_3d is in in_pts already
     if (use_device_setup(h)) {
         hipStream_t st = h->stream;
         h->in_cam.alloc((size_t)n_obs); h->in_pt.alloc((size_t)n_obs); h->in_uv.alloc((size_t)n_obs);
+        h->in_pts.alloc(3 * (size_t)n_pts);
         if (n_obs) {
-            HIP_TRY(hipMemcpyAsync(h->in_cam.p, cam_idx, (size_t)n_obs * sizeof(int64_t), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->in_pt.p, pt_idx, (size_t)n_obs * sizeof(int64_t), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->in_uv.p, points_2d, (size_t)n_obs * sizeof(double2), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->in_cam.p, cam_idx, (size_t)n_obs * sizeof(int64_t), hipMemcpyHostToDevice, st));
         }
-        tr.lap("upload of the caller's arrays");
-        device_setup(h, h->in_cam.p, h->in_pt.p, h->in_uv.p);
+        tr.lap("upload of the index arrays");
+        // The image points (half of the bytes) and the 3-D points go up from a second host thread
+        // on a stream of their own while the index work runs on the GPU; the structure needs them
+        // only at its very end (device_place_uv, do_set_params).
+        if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        hipError_t copy_err = hipSuccess;
+        std::thread copier([&] {
+            copy_err = hipSetDevice(h->device);
+            if (copy_err == hipSuccess && n_obs)
+                copy_err = hipMemcpyAsync(h->in_uv.p, points_2d, (size_t)n_obs * sizeof(double2), hipMemcpyHostToDevice, h->copy_stream);
+            if (copy_err == hipSuccess)
+                copy_err = hipMemcpyAsync(h->in_pts.p, points_3d, 3 * (size_t)n_pts * sizeof(double), hipMemcpyHostToDevice, h->copy_stream);
+            if (copy_err == hipSuccess) copy_err = hipStreamSynchronize(h->copy_stream);
+        });
+        try {
+            device_setup(h, h->in_cam.p, h->in_pt.p);
+        } catch (...) {
+            copier.join();
+            throw;
+        }
+        copier.join();
+        if (copy_err != hipSuccess) throw HipError{copy_err, "upload of points_2d / points_3d"};
         tr.lap("structure on the device");
+        device_place_uv(h, h->in_uv.p);
+        points_uploaded = true;
     } else {
         host_setup(h, cam_idx, pt_idx, points_2d);
     }
     alloc_work_buffers(h);
     tr.lap("work buffers");
-    do_set_params(h, camera_params, points_3d);
+    do_set_params(h, camera_params, points_3d, points_uploaded);
     tr.lap("parameters");
     h->has_problem = true;
 }
@@ -1547,7 +1573,8 @@ void do_set_problem_device(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, co
                            const double* points_2d_dev, const double* K) {
     begin_problem(h, n_cam, n_pts, n_obs, camera_params, points_3d, cam_idx_dev, pt_idx_dev, points_2d_dev, K);
     SetupTrace tr;
-    device_setup(h, cam_idx_dev, pt_idx_dev, reinterpret_cast<const double2*>(points_2d_dev));
+    device_setup(h, cam_idx_dev, pt_idx_dev);
+    device_place_uv(h, reinterpret_cast<const double2*>(points_2d_dev));
     tr.lap("structure on the device");
     alloc_work_buffers(h);
     do_set_params(h, camera_params, points_3d);

@@ -151,11 +151,10 @@ __global__ __launch_bounds__(kT) void k_renumber(const int* __restrict__ new2old
 // Point-major arrays: sorted position s (by the caller's point id, stable) -> its place in the
 // renumbered order, observations of a point keeping their order.
 __global__ __launch_bounds__(kT) void k_point_major(const unsigned* __restrict__ spt, const int* __restrict__ sidx,
-                                                    const unsigned* __restrict__ scam, const double2* __restrict__ uv,
+                                                    const unsigned* __restrict__ scam,
                                                     const int* __restrict__ pre, const int* __restrict__ old2new,
                                                     const int* __restrict__ pt_ptr, int pt_lo, int o_lo, int no,
-                                                    int* __restrict__ pm_cam, int* __restrict__ pm_pt, int* __restrict__ pm_orig,
-                                                    double2* __restrict__ pm_uv) {
+                                                    int* __restrict__ pm_cam, int* __restrict__ pm_pt, int* __restrict__ pm_orig) {
     const int t = blockIdx.x * kT + threadIdx.x;
     if (t >= no) return;
     const int s = o_lo + t;
@@ -166,18 +165,26 @@ __global__ __launch_bounds__(kT) void k_point_major(const unsigned* __restrict__
     pm_cam[j] = (int)scam[s];
     pm_pt[j] = q;
     pm_orig[j] = i;
-    pm_uv[j] = uv[i];
 }
 
-__global__ __launch_bounds__(kT) void k_camera_major(const int* __restrict__ cm2pm, const int* __restrict__ pm_pt,
-                                                     const double2* __restrict__ pm_uv, int no, int* __restrict__ pm2cm,
-                                                     int* __restrict__ cm_pt, double2* __restrict__ cm_uv) {
+__global__ __launch_bounds__(kT) void k_camera_major(const int* __restrict__ cm2pm, const int* __restrict__ pm_pt, int no,
+                                                     int* __restrict__ pm2cm, int* __restrict__ cm_pt) {
     const int k = blockIdx.x * kT + threadIdx.x;
     if (k >= no) return;
     const int j = cm2pm[k];
     pm2cm[j] = k;
     cm_pt[k] = pm_pt[j];
-    cm_uv[k] = pm_uv[j];
+}
+// The image points in both orders.  Apart from the index arrays this is all the structure needs
+// of the caller's data, and it is applied last, so that the upload of points_2d (half of the
+// bytes sfmba_set_problem moves over PCIe) can run while the index work above is on the GPU.
+__global__ __launch_bounds__(kT) void k_place_uv(const double2* __restrict__ uv, const int* __restrict__ pm_orig, const int* __restrict__ pm2cm,
+                                                 int no, double2* __restrict__ pm_uv, double2* __restrict__ cm_uv) {
+    const int j = blockIdx.x * kT + threadIdx.x;
+    if (j >= no) return;
+    const double2 v = uv[pm_orig[j]];
+    pm_uv[j] = v;
+    cm_uv[pm2cm[j]] = v;
 }
 
 // Pieces of at most `chunk` items per run: counts, then (after a scan) the pieces themselves.
@@ -344,7 +351,14 @@ bool explicit_affordable(int mode, int64_t n_pairs, int no) {
 
 }  // namespace
 
-void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const double2* uv) {
+void device_place_uv(H* h, const double2* uv) {
+    if (h->n_obs > 0)
+        hipLaunchKernelGGL(k_place_uv, dim3(grid_for((size_t)h->n_obs)), dim3(kT), 0, h->stream, uv, h->pm_orig.p, h->setup_pm2cm, h->n_obs,
+                           h->pm_uv.p, h->cm_uv.p);
+    HIP_TRY(hipGetLastError());
+}
+
+void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx) {
     hipStream_t st = h->stream;
     const int N = (int)h->n_obs_all, P = (int)h->n_pts_all, C = (int)h->n_cam;
     const int nr = std::max(1, h->opt.nranks), rk = nr > 1 ? h->opt.rank : 0;
@@ -418,12 +432,13 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const dou
     sort_pairs(h, min_cam, min_sorted, rocprim::counting_iterator<int>(0), h->new2old_dev.p, (size_t)np, bits_for((uint64_t)C));
     hipLaunchKernelGGL(k_renumber, dim3(grid_for((size_t)np + 1)), dim3(kT), 0, st, h->new2old_dev.p, pre, pt_lo, np, old2new, cnt_new);
     exclusive_scan(h, cnt_new, h->pt_ptr.p, (size_t)np + 1);
-    hipLaunchKernelGGL(k_point_major, dim3(grid_for(no)), dim3(kT), 0, st, spt, sidx, scam, uv, pre, old2new, h->pt_ptr.p,
-                               pt_lo, o_lo, no, h->pm_cam.p, h->pm_pt.p, h->pm_orig.p, h->pm_uv.p);
+    hipLaunchKernelGGL(k_point_major, dim3(grid_for(no)), dim3(kT), 0, st, spt, sidx, scam, pre, old2new, h->pt_ptr.p,
+                               pt_lo, o_lo, no, h->pm_cam.p, h->pm_pt.p, h->pm_orig.p);
     // camera-major: stable sort of the point-major list by camera
     sort_pairs(h, reinterpret_cast<const unsigned*>(h->pm_cam.p), cmk, rocprim::counting_iterator<int>(0), cm2pm, (size_t)no,
                bits_for((uint64_t)std::max(C - 1, 1)));
-    hipLaunchKernelGGL(k_camera_major, dim3(grid_for(no)), dim3(kT), 0, st, cm2pm, h->pm_pt.p, h->pm_uv.p, no, pm2cm, h->cm_pt.p, h->cm_uv.p);
+    hipLaunchKernelGGL(k_camera_major, dim3(grid_for(no)), dim3(kT), 0, st, cm2pm, h->pm_pt.p, no, pm2cm, h->cm_pt.p);
+    h->setup_pm2cm = pm2cm;          // (lives in ws[0] until the next set-up)
     hipLaunchKernelGGL(k_run_offsets, dim3(grid_for((size_t)no + 1)), dim3(kT), 0, st, cmk, no, C, cam_ptr);
     hipLaunchKernelGGL(k_piece_counts, dim3(grid_for((size_t)C + 1)), dim3(kT), 0, st, cam_ptr, C, h->chunk, nch);
     exclusive_scan(h, nch, h->cam_chunk_ptr.p, (size_t)C + 1);
