@@ -148,7 +148,8 @@ struct HandleData {
     DBuf<double4> s, s0;
     DBuf<double> px, pr, pz, pp[2], pq, qS;
     DBuf<PcgState> pcg;
-    PcgState* pcg_host = nullptr;          // pinned, [2]
+    PcgState* pcg_host = nullptr;          // pinned, [2]; [0] is also written directly by the single-launch PCG
+    double* scalars_host = nullptr;        // pinned, [SLOT_COUNT]: the scalar slots as the kernels write them
     hipEvent_t pcg_ev[2] = {nullptr, nullptr};
     DBuf<double> dot_part, scal_part, scalars;
     DBuf<double> tmp_a, tmp_b;             // API staging (residuals, Jacobian blocks, vectors)
@@ -207,6 +208,7 @@ struct HandleData {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
         if (pcg_host) (void)hipHostFree(pcg_host);
+        if (scalars_host) (void)hipHostFree(scalars_host);
         if (comm && comm_destroy) comm_destroy(comm);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);

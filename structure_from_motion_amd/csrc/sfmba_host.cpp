@@ -199,6 +199,8 @@ void refresh_dev(H* h) {
     d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p;
     d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp[0] = h->pp[0].p; d.pp[1] = h->pp[1].p; d.pq = h->pq.p; d.qS = h->qS.p;
     d.pcg = h->pcg.p; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
+    // (with a communicator the slots are summed over the ranks on the device and then copied)
+    d.scalars_host = h->has_comm() ? nullptr : h->scalars_host;
     d.dot_off = h->dot_off;
     d.n_ublk = h->n_ublk; d.n_pchunks = h->n_pchunks; d.nnzb = h->nnzb;
     d.ublk_r = h->ublk_r.p; d.ublk_c = h->ublk_c.p; d.ublk_chunk_ptr = h->ublk_chunk_ptr.p;
@@ -279,6 +281,12 @@ void allreduce(H* h, double* buf, size_t count) {
 }
 
 void read_scalars(H* h, double* out) {
+    if (!h->has_comm()) {
+        // every kernel that fills a slot has also written it to pinned host memory
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(out, h->scalars_host, SLOT_COUNT * sizeof(double));
+        return;
+    }
     HIP_TRY(hipMemcpyAsync(out, h->scalars.p, SLOT_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
 }
@@ -413,7 +421,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         // the whole solve in one launch; a breakdown of the single-reduction
         // recurrence or a barrier timeout falls through to the launch-per-iteration solver
         FusedPcg& f = h->fused;
-        f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = max_iter; f.flag_slot = nullptr;
+        f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = max_iter; f.flag_slot = nullptr; f.flag_host = nullptr;
         hipError_t e = hipErrorNotSupported;
         if (!h->fused_refused) {
             Scope t(h, F_BSR);
@@ -425,8 +433,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         PcgState st{};
         st.pad = 4;                             // launch refused
         if (e == hipSuccess) {
-            HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));        // the kernel wrote its state to pinned host memory
             st = h->pcg_host[0];
         } else if (!h->fused_refused) {
             if (h->trace_pcg) fprintf(stderr, "pcg single launch refused: %s\n", hipGetErrorString(e));
@@ -575,8 +582,9 @@ bool launch_linear_solve_async(H* h) {
     if (h->fused_refused && !h->has_comm()) { h->fused_pcg = false; return false; }
     const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
     FusedPcg& f = h->fused;
-    f.x = h->px.p; f.out = h->pcg.p; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
+    f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     f.flag_slot = h->scalars.p + SLOT_PCGFLAG;
+    f.flag_host = h->has_comm() ? nullptr : h->scalars_host + SLOT_PCGFLAG;
     hipError_t e = hipErrorNotSupported;
     if (!h->fused_refused) {
         Scope t(h, F_BSR);
@@ -596,8 +604,7 @@ bool launch_linear_solve_async(H* h) {
         HIP_TRY(hipMemcpyAsync(h->scalars.p + SLOT_PCGFLAG, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    HIP_TRY(hipMemcpyAsync(&h->pcg_host[0], h->pcg.p, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
-    return true;
+    return true;        // (the kernel writes its state straight into pcg_host[0])
 }
 
 // Step evaluation: back-substitution, retraction into the trial buffers, trial cost.
@@ -1662,6 +1669,7 @@ int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
     // this device's copy of the scratch array of sfmba_triangulate_noalloc (once per device)
     if (scratch_ptr(dev, &h->scratch) != hipSuccess) { delete h; return SFMBA_ERR_HIP; }
     if (hipHostMalloc((void**)&h->pcg_host, 2 * sizeof(PcgState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->scalars_host, SLOT_COUNT * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&h->pcg_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->pcg_ev[1], hipEventDisableTiming) != hipSuccess) {
         delete h;

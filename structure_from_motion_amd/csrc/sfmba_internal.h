@@ -56,6 +56,7 @@ struct FusedPcg {
                               // then one abort word; all bits set = not written / no abort
     PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout
     double* flag_slot;        // receives pad as a double (a scalar slot the ranks sum), may be null
+    double* flag_host;        // the same slot in pinned host memory, may be null
     double tol2;
     int max_iter;
     long long timeout_ticks;  // of the 100 MHz wall clock: any later poll
@@ -131,6 +132,8 @@ struct Dev {
     // scalars
     double* scal_part;  // [SLOT_COUNT][kMaxScalBlocks]
     double* scalars;    // [SLOT_COUNT]
+    double* scalars_host;   // the same slots in pinned host memory (written beside `scalars`, so that the
+                            // host needs no copy after its wait), or null
 };
 
 // Coarse space of the two-level PCG preconditioner (sfmba_coarse.hip): seven vectors per cluster

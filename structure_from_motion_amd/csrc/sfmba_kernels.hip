@@ -865,7 +865,10 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
 #pragma unroll
     for (int u = 0; u < 8; ++u) v = is_max ? fmax(v, a[u]) : v + a[u];
     double r = is_max ? block_max(v, red) : block_sum(v, red);
-    if (threadIdx.x == 0) d.scalars[slot] = r;
+    if (threadIdx.x == 0) {
+        d.scalars[slot] = r;
+        if (d.scalars_host) d.scalars_host[slot] = r;
+    }
 }
 
 // Per-camera sum of reprojection errors |projection - observation| at the current estimate,
@@ -922,7 +925,10 @@ __global__ __launch_bounds__(1024) void k_gmax_cam(Dev d) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) g = fmax(g, a[u]);
     const double m = block_max(g, red);
-    if (threadIdx.x == 0) d.scalars[SLOT_GMAX_CAM] = m;
+    if (threadIdx.x == 0) {
+        d.scalars[SLOT_GMAX_CAM] = m;
+        if (d.scalars_host) d.scalars_host[SLOT_GMAX_CAM] = m;
+    }
 }
 void launch_gmax_cam(const Dev& d, hipStream_t st) {
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_gmax_cam<Bal>), dim3(1), dim3(1024), 0, st, d);

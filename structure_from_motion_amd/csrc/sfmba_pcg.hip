@@ -700,6 +700,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
         st.ticks = (long long)wall_clock64() - t_start;
         *a.out = st;
         if (a.flag_slot) *a.flag_slot = (double)flag;
+        if (a.flag_host) *a.flag_host = (double)flag;
     }
 }
 
