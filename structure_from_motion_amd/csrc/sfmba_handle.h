@@ -108,6 +108,7 @@ struct HandleData {
     unsigned char* scratch = nullptr;     // this device's address of the library's scratch array
     bool has_problem = false;
     bool linearized = false;
+    bool lin_owed = false;         // the scalar slots of the last linearisation are still block partials
     double lin_lambda = 0.0;
     double damped_lambda = -1.0;   // damping for which Vinv and s0 are current
     bool have_v = false;           // V_p and g_p of the current linearisation are in memory

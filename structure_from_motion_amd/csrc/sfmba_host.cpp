@@ -304,10 +304,15 @@ void reduce_scalars(H* h, int first, int count) {
 // `lambda` is the damping of the step that will follow (0 = not known): the points are then damped
 // in the same pass and phase_damp(lambda) finds that done.
 // `grad_only`: the solve ends at this point and only its gradient norm is still wanted.
-void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false) {
+// `defer`: nobody on the device needs the scalar slots of this linearisation and the host will read
+// them only with those of the trial step that follows: they are finished by that step's launch
+// (phase_trial) instead of two small launches of their own.
+void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false, bool defer = false) {
     Scope t(h, F_LIN);
     refresh_dev(h);
-    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only, /*keep_v=*/false);
+    defer = defer && !h->has_comm();
+    launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only, /*keep_v=*/false, defer);
+    h->lin_owed = defer;
     h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
     h->have_v = !grad_only && !(lambda > 0.0);
     if (h->fuse_cm && h->explicit_schur && lambda > 0.0 && !grad_only) {
@@ -329,7 +334,7 @@ void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false) {
         HIP_TRY(hipMemcpyAsync(slots + h->opt.rank, h->scalars.p + SLOT_GMAX_PT, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         allreduce(h, h->UG.p, (size_t)h->n_cam * h->cv + nr);
     }
-    launch_gmax_cam(h->dev, h->stream);
+    if (!defer) launch_gmax_cam(h->dev, h->stream);
     h->linearized = false;
 }
 
@@ -612,7 +617,8 @@ void phase_trial(H* h, double* dp_out) {
     {
         Scope t(h, F_BACK);
         launch_cam_update(h->dev, h->px.p, h->stream);          // the trial cameras first:
-        launch_back_pm(h->dev, h->px.p, dp_out, h->stream);     // this pass also evaluates the trial cost
+        launch_back_pm(h->dev, h->px.p, dp_out, h->stream, h->lin_owed);     // this pass also evaluates the trial cost
+        h->lin_owed = false;
     }
     reduce_scalars(h, SLOT_MODEL, SLOT_PCGFLAG - SLOT_MODEL + 1);
 }
@@ -621,6 +627,7 @@ void phase_trial(H* h, double* dp_out) {
 // in place until the next linearisation, so they can also be read together with the scalars of
 // the trial step that follows.
 double read_lin_scalars(H* h, double* sc) {
+    if (h->lin_owed) { launch_lin_scalars(h->dev, h->stream); h->lin_owed = false; }
     std::vector<double> slots;
     if (h->has_comm()) {
         slots.resize(h->opt.nranks);
@@ -749,7 +756,7 @@ void do_solve(H* h, sfmba_stats* out) {
             nu = 2.0;
             cost = cost_new;
             // also the gradient norm at the new iterate; damps for the next step, unless this was the last
-            phase_linearize(h, lambda, ft || xt);
+            phase_linearize(h, lambda, ft || xt, /*defer=*/!talk && !(ft || xt));
             st.njev++;
             lin_pending = !talk;
             if (!lin_pending) g_norm = read_lin_scalars(h, sc);

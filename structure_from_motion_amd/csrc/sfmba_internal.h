@@ -170,7 +170,10 @@ void launch_residuals(const Dev& d, double* out_dev, hipStream_t st);
 void launch_jacobian_blocks(const Dev& d, double* jc_dev, double* jp_dev, hipStream_t st);
 // grad_only: cost and gradient maxima alone (the point a solve ends on); V, U, seeds are not produced
 // keep_v: also store V_p and g_p when the points are damped in the same pass (lambda > 0)
-void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only = false, bool keep_v = true);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
+// defer_scalars: the cost and gradient-maximum slots are left as block partials for a later
+// launch_back_pm(..., with_lin_scalars) or launch_lin_scalars (they are only read by the host)
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only = false, bool keep_v = true, bool defer_scalars = false);
+void launch_lin_scalars(const Dev& d, hipStream_t st);   // lambda > 0: damp the points in the same pass;   // seeds are only stored for the matrix-free Schur product
 void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only = false);               // chunk partials (NU + ND values)
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st);
 // launch_lin_cm + launch_sdiag_cm + both reductions in one pass (damping known, explicit matrix):
@@ -199,7 +202,7 @@ size_t pcg_fused_vector_words(int n_cam);
 // `armed`: the records already hold the sentinel (k_finish_diag did it)
 hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st);
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st);
-void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st);
+void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st, bool with_lin_scalars = false);
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st);
 void launch_gmax_cam(const Dev& d, hipStream_t st);
 void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st);   // [n_cam][2] = (sum of errors, count)

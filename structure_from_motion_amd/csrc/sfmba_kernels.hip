@@ -29,6 +29,11 @@ __device__ __forceinline__ void put_partial(const Dev& d, int slot, double v) {
 
 // Every observation kernel is a template over the camera model (sfmba_device.h) and launched for
 // the model of the problem.
+#define SFMBA_LAUNCH_T(d, KERNEL, grid, block, st, ...)                                               \
+    do {                                                                                              \
+        if ((d).model == MODEL_BAL) hipLaunchKernelGGL((KERNEL<Bal>), grid, block, 0, st, __VA_ARGS__);          \
+        else hipLaunchKernelGGL((KERNEL<Pinhole>), grid, block, 0, st, __VA_ARGS__);                 \
+    } while (0)
 #define SFMBA_LAUNCH(d, KERNEL, grid, st, ...)                                                        \
     do {                                                                                              \
         if ((d).model == MODEL_BAL) hipLaunchKernelGGL((KERNEL<Bal>), grid, dim3(kBlock), 0, st, __VA_ARGS__);   \
@@ -841,23 +846,34 @@ __global__ __launch_bounds__(kBlock) void k_cam_update(Dev d, const double* __re
     if (threadIdx.x == 0) { put_partial(d, SLOT_STEP2_CAM, a); put_partial(d, SLOT_X2_CAM, b); }
 }
 
-// scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per slot.  Two
-// runs of slots with their own partial counts can share a launch: workgroups [0, count_a) take the
-// slots from first_slot, the rest those from first_b (sums only).
-__global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, int nblocks, unsigned max_mask,
-                                                        int count_a, int first_b, int nblocks_b) {
+// scalars[slot] = sum (or max) of the block partials of that slot; one workgroup per job, so that
+// everything the host wants to read after a wait can be finished by ONE launch: the sums of the
+// trial step, the two slots k_cam_update left as block partials and, when the linearisation before
+// it left them unfinished (its values are only read by the host, together with these), its cost
+// and gradient maxima.
+struct FinalizeJobs {
+    int n;
+    int slot[12];
+    int nblocks[12];    // partials of the slot (kind 0, 1)
+    int kind[12];       // 0 sum, 1 max of block partials, 2 max |g_c| over the cameras out of UG
+};
+template <class M>
+__global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, FinalizeJobs jobs) {
     __shared__ double red[16];
-    const bool second = (int)blockIdx.x >= count_a;
-    const int slot = second ? first_b + (int)blockIdx.x - count_a : first_slot + (int)blockIdx.x;
-    const bool is_max = !second && ((max_mask >> blockIdx.x) & 1u);
-    if (second) nblocks = nblocks_b;
+    const int slot = jobs.slot[blockIdx.x], kind = jobs.kind[blockIdx.x];
+    const bool is_max = kind != 0;
+    const int nblocks = kind == 2 ? d.n_cam * M::ND : jobs.nblocks[blockIdx.x];
     const double* part = d.scal_part + (size_t)slot * kMaxScalBlocks;
     // eight loads in flight per thread (the order of the additions is fixed all the same)
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i0 = threadIdx.x; i0 < nblocks; i0 += 8 * 1024) {
         double x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; x[u] = i < nblocks ? part[i] : 0.0; }
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024;
+            if (kind == 2) x[u] = i < nblocks ? fabs(d.UG[M::NV * (size_t)(i / M::ND) + M::NU + (i % M::ND)]) : 0.0;
+            else x[u] = i < nblocks ? part[i] : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = is_max ? fmax(a[u], x[u]) : a[u] + x[u];
     }
@@ -869,6 +885,14 @@ __global__ __launch_bounds__(1024) void k_scal_finalize(Dev d, int first_slot, i
         d.scalars[slot] = r;
         if (d.scalars_host) d.scalars_host[slot] = r;
     }
+}
+static void add_job(FinalizeJobs& j, int slot, int nblocks, int kind) {
+    j.slot[j.n] = slot; j.nblocks[j.n] = nblocks; j.kind[j.n] = kind; ++j.n;
+}
+static void add_lin_jobs(const Dev& d, FinalizeJobs& j);
+static void run_jobs(const Dev& d, const FinalizeJobs& j, hipStream_t st) {
+    if (j.n == 0) return;
+    SFMBA_LAUNCH_T(d, k_scal_finalize, dim3(j.n), dim3(1024), st, d, j);
 }
 
 // Per-camera sum of reprojection errors |projection - observation| at the current estimate,
@@ -903,36 +927,11 @@ void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st) {
     launch_chunk_reduce(d, 2, out2, st);
 }
 
-// max |g_c| over the cameras (after the all-reduce of UG), straight into its scalar slot: one
-// workgroup, eight loads in flight per thread.
-template <class M>
-__global__ __launch_bounds__(1024) void k_gmax_cam(Dev d) {
-    constexpr int ND = M::ND;
-    __shared__ double red[16];
-    const int n = d.n_cam * ND;
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
-        double x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 1024;
-            x[u] = i < n ? fabs(d.UG[M::NV * (size_t)(i / ND) + M::NU + (i % ND)]) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = fmax(a[u], x[u]);
-    }
-    double g = 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) g = fmax(g, a[u]);
-    const double m = block_max(g, red);
-    if (threadIdx.x == 0) {
-        d.scalars[SLOT_GMAX_CAM] = m;
-        if (d.scalars_host) d.scalars_host[SLOT_GMAX_CAM] = m;
-    }
-}
+// max |g_c| over the cameras (after the all-reduce of UG), straight into its scalar slot.
 void launch_gmax_cam(const Dev& d, hipStream_t st) {
-    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_gmax_cam<Bal>), dim3(1), dim3(1024), 0, st, d);
-    else hipLaunchKernelGGL((k_gmax_cam<Pinhole>), dim3(1), dim3(1024), 0, st, d);
+    FinalizeJobs j{};
+    add_job(j, SLOT_GMAX_CAM, 0, 2);
+    run_jobs(d, j, st);
 }
 
 // a += b (in-process all-reduce of several handles)
@@ -981,7 +980,8 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     if (d.n_obs == 0) return;
     SFMBA_LAUNCH(d, k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), st, d, jc, jp);
 }
-void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only, bool keep_v) {
+int lin_pm_blocks(const Dev& d) { return cdiv(d.n_wtiles, (kBlock / 64) * kTilesPerWave); }
+void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only, bool keep_v, bool defer_scalars) {
     const int kv = keep_v || !(lambda > 0.0) ? 1 : 0;     // undamped: V and g_p are the only products
     const int nb = cdiv(d.n_wtiles, (kBlock / 64) * kTilesPerWave);
     if (nb > 0 && grad_only) {
@@ -993,7 +993,12 @@ void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st
         else if (store_seeds) hipLaunchKernelGGL((k_lin_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
         else hipLaunchKernelGGL((k_lin_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, lambda, kv);
     }
-    hipLaunchKernelGGL(k_scal_finalize, dim3(2), dim3(1024), 0, st, d, (int)SLOT_COST, nb, 2u, 2, 0, 0);
+    if (!defer_scalars) {
+        FinalizeJobs j{};
+        add_job(j, SLOT_COST, nb, 0);
+        add_job(j, SLOT_GMAX_PT, nb, 1);
+        run_jobs(d, j, st);
+    }
 }
 void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only) {
     if (d.n_chunks == 0) return;
@@ -1036,7 +1041,7 @@ void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hi
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st) {
     SFMBA_LAUNCH(d, k_schur_apply, dim3(blocks_cam(d)), st, d, x, lambda, y);
 }
-void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st) {
+void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st, bool with_lin_scalars) {
     const int nb = blocks_wtile(d);
     static const bool stage = !(getenv("SFMBA_STAGE_CAMS") && atoi(getenv("SFMBA_STAGE_CAMS")) == 0);
     if (nb <= 0) return;
@@ -1048,7 +1053,23 @@ void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t 
         else hipLaunchKernelGGL((k_back_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
     }
     // MODEL .. NONFINITE, and with them the two slots k_cam_update left as block partials
-    hipLaunchKernelGGL(k_scal_finalize, dim3(7), dim3(1024), 0, st, d, (int)SLOT_MODEL, nb, 0u, 5, (int)SLOT_STEP2_CAM, blocks_cam(d));
+    FinalizeJobs j{};
+    for (int i = 0; i < 5; ++i) add_job(j, SLOT_MODEL + i, nb, 0);
+    add_job(j, SLOT_STEP2_CAM, blocks_cam(d), 0);
+    add_job(j, SLOT_X2_CAM, blocks_cam(d), 0);
+    if (with_lin_scalars) add_lin_jobs(d, j);
+    run_jobs(d, j, st);
+}
+// The scalars a linearisation whose launch_lin_pm deferred them still owes: cost, max |g_p|, max |g_c|.
+static void add_lin_jobs(const Dev& d, FinalizeJobs& j) {
+    add_job(j, SLOT_COST, lin_pm_blocks(d), 0);
+    add_job(j, SLOT_GMAX_PT, lin_pm_blocks(d), 1);
+    add_job(j, SLOT_GMAX_CAM, 0, 2);
+}
+void launch_lin_scalars(const Dev& d, hipStream_t st) {
+    FinalizeJobs j{};
+    add_lin_jobs(d, j);
+    run_jobs(d, j, st);
 }
 void launch_cam_update(const Dev& d, const double* dc, hipStream_t st) {
     // (its two scalar slots are finalised together with those of k_back_pm, which always follows)
