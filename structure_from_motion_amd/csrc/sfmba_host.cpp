@@ -1215,6 +1215,11 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
             f.timeout_ticks = 20000000LL;         // 0.2 s of the 100 MHz wall clock
             f.admit_ticks = 200000LL;             // 2 ms
             f.blocks = blocks;
+            // the pipelined variant wants one row per wavefront at most and rows of at most 64 blocks
+            int longest = 0;
+            for (int c = 0; c < n_cam; ++c) longest = std::max(longest, bsr_ptr[c + 1] - bsr_ptr[c]);
+            f.pipelined = n_cam <= blocks * rows && longest <= 64 ? 1 : 0;
+            if (const char* e = getenv("SFMBA_PCG_PIPE")) f.pipelined = f.pipelined && atoi(e) != 0;
             h->fused_blocks = blocks;
             h->fused_pcg = true;
             h->fused_refused = false;

@@ -62,6 +62,7 @@ struct FusedPcg {
     long long timeout_ticks;  // of the 100 MHz wall clock: any later poll
     long long admit_ticks;    // the first poll (all workgroups resident and started)
     int blocks;               // workgroups of the launch
+    int pipelined;            // 1: k_pcg_pipe (reduction overlapped with the product), 0: k_pcg_fused
 };
 constexpr int kPcgSlots = 4;      // rotating generation slots of the single-launch PCG
 constexpr int kPcgVecRec = 18;    // r[6] w[6] s[6] of one camera and generation
