@@ -227,7 +227,9 @@ def main():
     if ps.pcg_single_launch:
         # single-launch PCG: the matrix lives in registers; one iteration moves the 18-word
         # record of every gathered column and of every row written (through memory, past L2)
-        ab["bsr"] = 144 * ps.schur_blocks + 144 * p["n_cameras"]
+        # (pipelined kernel: the 6-word w record instead)
+        rec = 48 if ps.pcg_pipelined else 144
+        ab["bsr"] = rec * ps.schur_blocks + rec * p["n_cameras"]
     else:
         cd = 9 if bal else 6
         ab["bsr"] = (8 * cd * cd + 4) * ps.schur_blocks + 40 * cd * p["n_cameras"]
@@ -250,7 +252,8 @@ def main():
         return ab[f] / avg_s / 1e9 if avg_s > 0 else 0.0
 
     kernel_name = {"pairs": "k_schur_pairs", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm",
-                   "bsr": "k_pcg_fused (per PCG iteration)" if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
+                   "bsr": ("k_pcg_pipe (per PCG iteration)" if ps.pcg_pipelined else "k_pcg_fused (per PCG iteration)")
+                   if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
     traffic = None

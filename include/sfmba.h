@@ -79,7 +79,11 @@ typedef struct sfmba_options {
     /* PCG on the explicit reduced matrix: 0 = choose (single launch when the device can give
      * every camera row a wavefront of its own), 1 = two launches per iteration, 2 = the whole
      * solve in one launch whose workgroups synchronise through memory (falls back to 1 per solve
-     * on a breakdown of its recurrence or when its workgroups do not all become resident). */
+     * on a breakdown of its recurrence or when its workgroups do not all become resident).  The
+     * single launch runs pipelined conjugate gradients (the global sums of an iteration travel
+     * while its matrix-vector product is formed) when every wavefront owns at most one row and no
+     * row has more than 64 blocks, the single-reduction form of Chronopoulos and Gear otherwise;
+     * same iterates in exact arithmetic. */
     int32_t pcg_mode;
     int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
     int32_t camera_model;     /* enum sfmba_camera_model; default SFMBA_CAMERA_PINHOLE */
@@ -150,6 +154,8 @@ typedef struct sfmba_stats {
     int64_t pcg_coarse_solves;                 /* linear solves preconditioned with the coarse space */
     int64_t pcg_coarse_dim;                    /* coarse unknowns (7 x clusters), 0 = no coarse space built */
     double ms_comm;       int64_t n_comm;      /* all-reduces between the ranks (stream time: the wait for the slowest rank included) */
+    int64_t pcg_pipelined;                     /* 1: the single-launch solves ran the pipelined-CG kernel (every camera row on a
+                                                  wavefront of its own, rows of at most 64 blocks), 0: the plain one */
 } sfmba_stats;
 
 /* Fill *opts with the defaults listed above. */

@@ -801,6 +801,7 @@ void do_solve(H* h, sfmba_stats* out) {
     st.schur_chunks = h->explicit_schur ? h->n_pchunks : 0;
     st.ms_pairs = h->fam_ms[F_PAIRS]; st.n_pairs = h->fam_n[F_PAIRS];
     st.ms_comm = h->fam_ms[F_COMM]; st.n_comm = h->fam_n[F_COMM];
+    st.pcg_pipelined = h->fused_pcg && h->fused.pipelined ? 1 : 0;
     st.pcg_single_launch = h->fused_solves; st.pcg_single_fallbacks = h->fused_fallbacks;
     st.pcg_coarse_solves = h->coarse_solves;
     st.pcg_coarse_dim = h->explicit_schur && h->coarse_built ? h->coarse.n : 0;

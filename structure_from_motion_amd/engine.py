@@ -88,6 +88,7 @@ class Stats(C.Structure):
         ("pcg_single_launch", C.c_int64), ("pcg_single_fallbacks", C.c_int64),
         ("pcg_coarse_solves", C.c_int64), ("pcg_coarse_dim", C.c_int64),
         ("ms_comm", C.c_double), ("n_comm", C.c_int64),
+        ("pcg_pipelined", C.c_int64),
     ]
 
     def as_dict(self):

@@ -410,3 +410,21 @@ def test_blocks_cannot_be_read_from_inside_a_solve():
         eng.linearize(1e-4)
         U, gc, V, gp = eng.get_blocks()
         assert np.isfinite(U).all() and np.isfinite(V).all()
+
+
+def test_both_single_launch_pcg_kernels_agree(monkeypatch):
+    # pipelined conjugate gradients (default where every camera row has a wavefront of its own)
+    # against the single-reduction kernel it replaces: same iterates in exact arithmetic
+    p = syn.make_shape("venice", seed=3, scale=0.05)
+    out = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("SFMBA_PCG_PIPE", pipe)
+        with Engine(pcg_mode=2) as eng:
+            eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
+            out[pipe] = eng.solve()
+    a, b = out["1"], out["0"]
+    assert a.pcg_pipelined == 1 and b.pcg_pipelined == 0
+    assert a.pcg_single_launch == a.iterations and b.pcg_single_launch == b.iterations
+    assert (a.status, a.iterations) == (b.status, b.iterations)
+    assert abs(a.pcg_iterations - b.pcg_iterations) <= 2
+    assert abs(a.final_cost - b.final_cost) <= 1e-10 * b.final_cost
