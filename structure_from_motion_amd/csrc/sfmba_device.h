@@ -640,10 +640,14 @@ __device__ __forceinline__ void seg_scan(double (&v)[N], int key, int lane) {
         const int ku = __shfl_up(key, off, 64);
         const bool take = lane >= off && ku == key;
         if (!__any(take)) break;
+        // (one fused multiply-add per value instead of an add and two selects: v + 1 u and v + 0 u
+        // are exact for finite u, and a non-finite value anywhere in a linearisation fails the
+        // solve whichever point it reaches)
+        const double m = take ? 1.0 : 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const double u = __shfl_up(v[i], off, 64);
-            if (take) v[i] += u;
+            v[i] = fma(u, m, v[i]);
         }
     }
 }
