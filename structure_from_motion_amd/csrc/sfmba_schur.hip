@@ -161,19 +161,27 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d, int nn) {
 // Cholesky factor, the inverse (block-Jacobi preconditioner), the reduced right-hand side
 // rhs = -g_c + sum W Vinv g_p and, for the single-launch PCG, the scaling F = L^-1, bhat = F rhs,
 // the scaled diagonal block F S_cc F' and the armed (all bits set) exchange buffers.
+//
+// A camera's sums and blocks are rows of 27 to 81 doubles, so every load and store of a thread
+// touches a cache line of its own: what bounds the kernel is the number of line accesses one
+// compute unit's vector cache serves per cycle.  One-wavefront workgroups in which only the first
+// kDiagCams lanes own a camera spread the cameras over all compute units (1 778 cameras: 112
+// workgroups instead of 7; 22 -> 7 us per launch).
+constexpr int kDiagCams = 16;
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f) {
+__global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f) {
     constexpr int ND = M::ND, NU = M::NU, NV = M::NV, NN = ND * ND;
-    const int c = blockIdx.x * kBlock + threadIdx.x;
     if (f.F != nullptr) {
         // arm the exchange buffers of the single-launch PCG: every word all bits set
         unsigned long long* vw = reinterpret_cast<unsigned long long*>(f.vec);
         unsigned long long* dw = reinterpret_cast<unsigned long long*>(f.dots);
         const size_t nv = (size_t)kPcgSlots * d.n_cam * kPcgVecRec, nd = 2 * (size_t)kPcgSlots * f.blocks + 1;
-        for (size_t i = c; i < nv; i += (size_t)gridDim.x * kBlock) vw[i] = ~0ull;
-        for (size_t i = c; i < nd; i += (size_t)gridDim.x * kBlock) dw[i] = ~0ull;
+        const size_t t = blockIdx.x * 64 + threadIdx.x, nt = (size_t)gridDim.x * 64;
+        for (size_t i = t; i < nv; i += nt) vw[i] = ~0ull;
+        for (size_t i = t; i < nd; i += nt) dw[i] = ~0ull;
     }
-    if (c >= d.n_cam) return;
+    const int c = blockIdx.x * kDiagCams + threadIdx.x;
+    if (threadIdx.x >= kDiagCams || c >= d.n_cam) return;
     const double* U = d.UG + NV * (size_t)c;
     const double* T = tpart + NV * (size_t)c;          // packed upper sum W Vinv W' | sum W Vinv g_p
     const double* B = d.Bsum + NN * (size_t)d.ublk_diag[c];   // pairs of two observations of one point in this camera
@@ -346,12 +354,11 @@ void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const
     if (scaled) f = *scaled;
     const int nn = cam_dim(d) * cam_dim(d);
     if (d.model == MODEL_BAL) {
-        hipLaunchKernelGGL((k_finish_diag<Bal>), dim3(cdiv(d.n_cam, kBlock)), dim3(kBlock), 0, st, d, lambda, tpart, f);
+        hipLaunchKernelGGL((k_finish_diag<Bal>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f);
         if (d.n_ublk > 0)
             hipLaunchKernelGGL((k_finish_offdiag<Bal::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
     } else {
-        // (with the single-launch PCG the grid is widened: its threads also arm the exchange buffers)
-        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(std::max(cdiv(d.n_cam, kBlock), scaled ? 128 : 1)), dim3(kBlock), 0, st, d, lambda, tpart, f);
+        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f);
         if (d.n_ublk > 0)
             hipLaunchKernelGGL((k_finish_offdiag<Pinhole::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
     }
