@@ -116,8 +116,9 @@ typedef struct sfmba_options {
  *   SFMBA_CAMERA_BAL      P = 9, D = 9: rotation vector, translation, f, k1, k2 of the "Bundle
  *       Adjustment in the Large" files; pixel = f (1 + k1 n + k2 n^2) p with p = -(R X + t)[:2] /
  *       (R X + t)[2], n = |p|^2 (ba_test.py:62-100); tangent (dw, dt, df, dk1, dk2); K is not
- *       read and may be NULL.  Every linear solver is available except the single-launch PCG
- *       (pcg_mode is ignored: the explicit matrix is solved with a launch per iteration). */
+ *       read and may be NULL.  Every linear solver is available; of the single-launch PCG only the
+ *       pipelined form exists for this model, so where that does not apply (see pcg_mode) the
+ *       explicit matrix is solved with a launch per iteration. */
 enum sfmba_camera_model { SFMBA_CAMERA_PINHOLE = 0, SFMBA_CAMERA_BAL = 1 };
 
 typedef struct sfmba_stats {

@@ -1188,7 +1188,7 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     if (const char* e = getenv("SFMBA_PCG_COARSE")) coarse = atoi(e);
     if (coarse > 0) pcg_mode = 1;           // the coarse space belongs to the launch-per-iteration solver
     h->fused_pcg = false;
-    if (pcg_mode != 1 && !want_dense && h->model == MODEL_PINHOLE) {     // (written for 6x6 blocks)
+    if (pcg_mode != 1 && !want_dense) {
         const int cap = pcg_fused_max_blocks(h->device);
         const int rows = pcg_fused_rows_per_block();
         int blocks = std::min(cap, (n_cam + rows - 1) / rows);
@@ -1198,15 +1198,23 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         // registers: beyond that an iteration streams the matrix and is bound by bandwidth, not by
         // launches (Final shape, 13 682 cameras: 48 us per iteration either way)
         if (pcg_mode == 0 && n_cam > cap * rows) blocks = 0;
+        // the pipelined variant wants one row per wavefront at most and rows of at most 64 blocks;
+        // it is the only one written for blocks other than 6 x 6
+        int longest = 0;
+        for (int c = 0; c < n_cam; ++c) longest = std::max(longest, bsr_ptr[c + 1] - bsr_ptr[c]);
+        bool pipelined = n_cam <= blocks * rows && longest <= 64;
+        if (const char* e = getenv("SFMBA_PCG_PIPE")) pipelined = pipelined && atoi(e) != 0;
+        if (h->cd != 6 && !pipelined) blocks = 0;
         if (blocks > 0) {
-            const size_t v = (size_t)n_cam * 6;
-            h->Shat.alloc((size_t)nnzb * 36);
-            h->Fscale.alloc((size_t)n_cam * 36);
+            const size_t v = (size_t)n_cam * h->cd;
+            h->Shat.alloc((size_t)nnzb * nn);
+            h->Fscale.alloc((size_t)n_cam * nn);
             h->bhat.alloc(v);
             h->fvec.alloc(pcg_fused_vector_words(n_cam) + 2 * v);
             h->fdots.alloc((pcg_fused_record_words(blocks) + 1) / 2);
             FusedPcg& f = h->fused;
             f.n_cam = n_cam;
+            f.nd = h->cd;
             f.bsr_ptr = h->bsr_ptr.p; f.bsr_col = h->bsr_col.p; f.bsr_diag = h->bsr_diag.p;
             f.Shat = h->Shat.p; f.F = h->Fscale.p; f.bhat = h->bhat.p;
             f.vec = h->fvec.p;
@@ -1216,11 +1224,7 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
             f.timeout_ticks = 20000000LL;         // 0.2 s of the 100 MHz wall clock
             f.admit_ticks = 200000LL;             // 2 ms
             f.blocks = blocks;
-            // the pipelined variant wants one row per wavefront at most and rows of at most 64 blocks
-            int longest = 0;
-            for (int c = 0; c < n_cam; ++c) longest = std::max(longest, bsr_ptr[c + 1] - bsr_ptr[c]);
-            f.pipelined = n_cam <= blocks * rows && longest <= 64 ? 1 : 0;
-            if (const char* e = getenv("SFMBA_PCG_PIPE")) f.pipelined = f.pipelined && atoi(e) != 0;
+            f.pipelined = pipelined ? 1 : 0;
             h->fused_blocks = blocks;
             h->fused_pcg = true;
             h->fused_refused = false;

@@ -40,18 +40,21 @@ struct PcgState {
     long long ticks;  // single-launch solver: duration in ticks of the 100 MHz wall clock
 };
 
-// Arguments of the single-launch PCG (k_pcg_fused): the symmetrically scaled system
+// Arguments of the single-launch PCG (k_pcg_fused, k_pcg_pipe): the symmetrically scaled system
 // Shat = F S F', bhat = F rhs with F = L^-1 of the diagonal blocks (S_cc = L L'), so that the
-// block-Jacobi preconditioner becomes the identity and x = F' xhat.
+// block-Jacobi preconditioner becomes the identity and x = F' xhat.  nd = tangent numbers per
+// camera: 6, or 9 (k_pcg_pipe only).
 struct FusedPcg {
     int n_cam;
+    int nd;
     const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;
-    const double* Shat;       // [nnzb][36] (6x6 blocks only)
-    const double* F;          // [n_cam][36] lower triangular, row-major
-    const double* bhat;       // [n_cam][6]
+    const double* Shat;       // [nnzb][nd nd]
+    const double* F;          // [n_cam][nd nd] lower triangular, row-major
+    const double* bhat;       // [n_cam][nd]
     double* vec;              // [4][n_cam][18] (r, w, s) records in rotating generation slots
-    double* p; double* xh;    // [n_cam][6], touched by the owning wavefront only
-    double* x;                // [n_cam][6] solution of the unscaled system
+                              // (k_pcg_pipe: [4][n_cam][nd], w only)
+    double* p; double* xh;    // [n_cam][6], touched by the owning wavefront only (k_pcg_fused)
+    double* x;                // [n_cam][nd] solution of the unscaled system
     double2* dots;            // [4][gridDim.x] per-workgroup (r'r, w'r) records in rotating slots,
                               // then one abort word; all bits set = not written / no abort
     PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout

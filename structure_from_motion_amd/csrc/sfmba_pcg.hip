@@ -718,32 +718,76 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
 // checked by the host: every wavefront owns at most one camera row, a row has at most 64 blocks.
 // Same iterates as k_pcg_fused in exact arithmetic (measured: the same iteration counts), 3.3
 // instead of 4.2 us per iteration at 1 778 cameras.
-constexpr int kPipeRec = 6;
-constexpr int kPipeSteps = (64 * kPipeRec) / 64;
+// Written for ND x ND blocks, ND = 6 (pinhole camera) or 9 (camera with its own intrinsics: the
+// block of a lane takes 162 of the 256 registers a wavefront may use at two per SIMD).
 
+// Sum of the per-lane ND-vectors over the wavefront through its LDS tile (64 ND + 64 doubles);
+// lane k < ND receives component k.  Two levels in fixed order, as row_total: kParts = 64 / ND
+// groups of ND lanes add kRows = ceil(64 / kParts) rows each, then lane k adds the parts.
+template <int ND>
+__device__ __forceinline__ double row_total_n(const double (&y)[ND], int lane, double* tile) {
+    if constexpr (ND == 6) {
+        return row_total(y, lane, tile);
+    } else {
+        constexpr int kParts = 64 / ND, kRows = (64 + kParts - 1) / kParts;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < ND; ++i) tile[ND * lane + i] = y[i];
+        __builtin_amdgcn_wave_barrier();
+        const int k = lane % ND, part = lane / ND;
+        double q = 0.0;
+        if (part < kParts) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r)
+                if (kRows * part + r < 64) q += tile[ND * (kRows * part + r) + k];
+            tile[64 * ND + lane] = q;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ND) {
+            q = 0.0;
+#pragma unroll
+            for (int p = 0; p < kParts; ++p) q += tile[64 * ND + ND * p + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        return q;
+    }
+}
+
+template <int ND>
 __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
+    constexpr int kPipeRec = ND, kPipeSteps = ND, NN = ND * ND;
     __shared__ double red[2 * kFusedWaves];
     __shared__ double2 dotbuf[kFusedWaves];
-    __shared__ __attribute__((aligned(16))) double tiles[kFusedWaves][64 * 6 + 64];
+    __shared__ __attribute__((aligned(16))) double tiles[kFusedWaves][64 * ND + 64];
     __shared__ int fail_lds;
+    // With 9 x 9 blocks the registers are full: the four vectors only the owning lanes update
+    // (s, p, z, x) and the gather offsets then live in LDS.
+    constexpr bool kLean = ND > 6;
+    __shared__ double own_lds[kLean ? kFusedWaves * 4 * 16 : 1];
+    __shared__ int off_lds[kLean ? kFusedWaves * kPipeSteps * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int G = gridDim.x, row = blockIdx.x * kFusedWaves + w;
     const bool mine = row < a.n_cam;
     const long long t_start = (long long)wall_clock64();
     unsigned long long* drec = reinterpret_cast<unsigned long long*>(a.dots);
     double* tile = tiles[w];
+    double* own = own_lds + (kLean ? w * 4 * 16 : 0);
+    int* offs = off_lds + (kLean ? w * kPipeSteps * 64 : 0);
     Poller poll;
     poll.abort_word = drec + 2 * kSlots * (size_t)G;
     poll.deadline = t_start + a.admit_ticks;
     const size_t gen_stride = (size_t)a.n_cam * kPipeRec;
     if (tid == 0) fail_lds = 0;
+    if constexpr (kLean) {
+        if (lane < 16) { own[lane] = 0.0; own[16 + lane] = 0.0; own[32 + lane] = 0.0; own[48 + lane] = 0.0; }
+    }
 
     // this lane's block of the row and the word offsets of the cooperative gather
     int nb = 0;
     int off[kPipeSteps];
-    double S[36];
+    double S[NN];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) S[i] = 0.0;
+    for (int i = 0; i < NN; ++i) S[i] = 0.0;
 #pragma unroll
     for (int t = 0; t < kPipeSteps; ++t) off[t] = -1;
     double o_r = 0.0, o_w = 0.0, o_s = 0.0, o_p = 0.0, o_z = 0.0, o_x = 0.0;
@@ -755,31 +799,51 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
             const int e = 64 * t + lane, blk = e / kPipeRec, j = e - kPipeRec * blk;
             off[t] = blk < nb ? a.bsr_col[b0 + blk] * kPipeRec + j : -1;
         }
-        double y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double y[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) y[i] = 0.0;
         if (lane < nb) {
-            const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)(b0 + lane));
-#pragma unroll
-            for (int i = 0; i < 18; ++i) { const double2 v = sp[i]; S[2 * i] = v.x; S[2 * i + 1] = v.y; }
             // generation 0: r0 = bhat is in memory, w0 = Shat r0 needs no exchange
-            const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b0 + lane]);
-            const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
-            const double rc[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+            double rc[ND];
+            if constexpr (ND == 6) {
+                const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)(b0 + lane));
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-                y[i] = S[6 * i] * rc[0] + S[6 * i + 1] * rc[1] + S[6 * i + 2] * rc[2] + S[6 * i + 3] * rc[3] + S[6 * i + 4] * rc[4] + S[6 * i + 5] * rc[5];
+                for (int i = 0; i < 18; ++i) { const double2 v = sp[i]; S[2 * i] = v.x; S[2 * i + 1] = v.y; }
+                const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b0 + lane]);
+                const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
+                rc[0] = r0.x; rc[1] = r0.y; rc[2] = r1.x; rc[3] = r1.y; rc[4] = r2.x; rc[5] = r2.y;
+            } else {
+                const double* sp = a.Shat + NN * (size_t)(b0 + lane);
+#pragma unroll
+                for (int i = 0; i < NN; ++i) S[i] = sp[i];
+                const double* rv = a.bhat + ND * (size_t)a.bsr_col[b0 + lane];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) rc[i] = rv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                double t = S[ND * i] * rc[0];
+#pragma unroll
+                for (int j = 1; j < ND; ++j) t += S[ND * i + j] * rc[j];
+                y[i] = t;
+            }
         }
-        const double q = row_total(y, lane, tile);
-        if (lane < 6) { o_r = a.bhat[6 * (size_t)row + lane]; o_w = q; }
+        const double q = row_total_n<ND>(y, lane, tile);
+        if (lane < ND) { o_r = a.bhat[ND * (size_t)row + lane]; o_w = q; }
+    }
+    if constexpr (kLean) {
+#pragma unroll
+        for (int t = 0; t < kPipeSteps; ++t) offs[64 * t + lane] = off[t];
     }
 
     auto publish = [&](double g, double dl, int gen) {
         __builtin_amdgcn_wave_barrier();
-        if (lane < 6) reinterpret_cast<double2*>(tile)[lane] = make_double2(g, dl);
+        if (lane < ND) reinterpret_cast<double2*>(tile)[lane] = make_double2(g, dl);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             double sg = 0.0, sd = 0.0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { const double2 v = reinterpret_cast<const double2*>(tile)[i]; sg += v.x; sd += v.y; }
+            for (int i = 0; i < ND; ++i) { const double2 v = reinterpret_cast<const double2*>(tile)[i]; sg += v.x; sd += v.y; }
             red[w] = sg; red[kFusedWaves + w] = sd;
         }
         block_barrier();
@@ -800,7 +864,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
         // the stores of the iteration before (the re-arming among them, a whole iteration old by
         // now) have landed before anything of this generation is stored
         __builtin_amdgcn_s_waitcnt(0);
-        if (mine && lane < 6) st_shared(vcur + (size_t)row * kPipeRec + lane, o_w);
+        if (mine && lane < ND) st_shared(vcur + (size_t)row * kPipeRec + lane, o_w);
         publish(o_r * o_r, o_w * o_r, it);
         // Everybody's (gamma, delta) of generation it - 1 were collected in the iteration before,
         // so everybody has published that generation and left generation it - 2: re-arm this
@@ -810,7 +874,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
         // seen this workgroup's (gamma, delta) of generation it + 1.
         if (it >= 2) {
             double* arm = a.vec + (size_t)((it - 2) % kSlots) * gen_stride;
-            if (mine && lane < 6) st_word(reinterpret_cast<unsigned long long*>(arm + (size_t)row * kPipeRec) + lane, kSentinel);
+            if (mine && lane < ND) st_word(reinterpret_cast<unsigned long long*>(arm + (size_t)row * kPipeRec) + lane, kSentinel);
             if (tid == 0) {
                 unsigned long long* rec = drec + 2 * ((size_t)((it - 2) % kSlots) * G + blockIdx.x);
                 st_word(rec, kSentinel);
@@ -821,26 +885,39 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
         bool okw = true;
         for (int spins = 1;; ++spins) {
             bool ok = true;
-            double val[kPipeSteps];
+            constexpr int kFlight = ND == 6 ? 6 : 3;        // loads in flight (register budget)
 #pragma unroll
-            for (int t = 0; t < kPipeSteps; ++t)
-                if (off[t] >= 0) val[t] = ld_shared(vcur + off[t]);
+            for (int t0 = 0; t0 < kPipeSteps; t0 += kFlight) {
+                double val[kFlight];
+                int o[kFlight];
 #pragma unroll
-            for (int t = 0; t < kPipeSteps; ++t)
-                if (off[t] >= 0) { ok = ok && !is_sentinel(val[t]); tile[64 * t + lane] = val[t]; }
+                for (int t = 0; t < kFlight; ++t) o[t] = kLean ? offs[64 * (t0 + t) + lane] : off[t0 + t];
+#pragma unroll
+                for (int t = 0; t < kFlight; ++t)
+                    if (o[t] >= 0) val[t] = ld_shared(vcur + o[t]);
+#pragma unroll
+                for (int t = 0; t < kFlight; ++t)
+                    if (o[t] >= 0) { ok = ok && !is_sentinel(val[t]); tile[64 * (t0 + t) + lane] = val[t]; }
+            }
             if (__all(ok)) break;
             if (poll.expired(spins)) { okw = false; break; }
         }
-        double y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double y[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) y[i] = 0.0;
         __builtin_amdgcn_wave_barrier();
         if (okw && lane < nb) {
+            // (column by column: one component of w in a register at a time; per row the same
+            // sequence of operations as a dot product taken left to right)
             const double* u = tile + kPipeRec * lane;
-            const double wc[6] = {u[0], u[1], u[2], u[3], u[4], u[5]};
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-                y[i] = S[6 * i] * wc[0] + S[6 * i + 1] * wc[1] + S[6 * i + 2] * wc[2] + S[6 * i + 3] * wc[3] + S[6 * i + 4] * wc[4] + S[6 * i + 5] * wc[5];
+            for (int j = 0; j < ND; ++j) {
+                const double wj = u[j];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) y[i] = j == 0 ? S[ND * i] * wj : fma(S[ND * i + j], wj, y[i]);
+            }
         }
-        const double q = row_total(y, lane, tile);
+        const double q = row_total_n<ND>(y, lane, tile);
         // every workgroup's (gamma, delta) of this generation: published before the product above
         // (requesting them before the product and looking at them after it was measured: slower)
         double sum_g = 0.0, sum_d = 0.0;
@@ -883,13 +960,15 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
         const double alpha = gam / den;
         gam_prev = gam;
         alpha_prev = alpha;
-        if (lane < 6) {
+        if (lane < ND) {
+            if constexpr (kLean) { o_z = own[lane]; o_s = own[16 + lane]; o_p = own[32 + lane]; o_x = own[48 + lane]; }
             o_z = fma(beta, o_z, q);
             o_s = fma(beta, o_s, o_w);
             o_p = fma(beta, o_p, o_r);
             o_x = fma(alpha, o_p, o_x);
             o_r = fma(-alpha, o_s, o_r);
             o_w = fma(-alpha, o_z, o_w);
+            if constexpr (kLean) { own[lane] = o_z; own[16 + lane] = o_s; own[32 + lane] = o_p; own[48 + lane] = o_x; }
         }
         ++it;
     }
@@ -897,11 +976,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
     if (flag != 2 && mine) {
         double val = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double xj = __shfl(o_x, j, 64);
-            if (lane < 6) val += a.F[36 * (size_t)row + 6 * j + lane] * xj;
+        for (int j = 0; j < ND; ++j) {
+            const double xj = kLean ? own[48 + j] : __shfl(o_x, j, 64);
+            if (lane < ND) val += a.F[NN * (size_t)row + ND * j + lane] * xj;
         }
-        if (lane < 6) a.x[6 * (size_t)row + lane] = val;
+        if (lane < ND) a.x[ND * (size_t)row + lane] = val;
     }
     if (blockIdx.x == 0 && tid == 0) {
         PcgState st;
@@ -936,7 +1015,9 @@ hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     FusedPcg arg = f;
-    if (f.pipelined) hipLaunchKernelGGL(k_pcg_pipe, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    if (f.nd != 6 && !(f.nd == 9 && f.pipelined)) return hipErrorInvalidValue;
+    if (f.pipelined && f.nd == 9) hipLaunchKernelGGL((k_pcg_pipe<9>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    else if (f.pipelined) hipLaunchKernelGGL((k_pcg_pipe<6>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     else hipLaunchKernelGGL(k_pcg_fused, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     return hipGetLastError();
 }

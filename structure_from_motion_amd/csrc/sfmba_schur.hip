@@ -226,36 +226,32 @@ __global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const 
         r[i] = -g[i] + T[NU + i];
         d.rhs[ND * (size_t)c + i] = r[i];
     }
-    if constexpr (ND == 6) {        // the single-launch PCG is written for 6x6 blocks
-        if (f.F == nullptr) return;
-        double* Fo = const_cast<double*>(f.F) + 36 * (size_t)c;
-        double* bo = const_cast<double*>(f.bhat) + 6 * (size_t)c;
-        double FS[6][6];                // F S
-    #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double v = 0.0;
-    #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const double lij = j <= i ? Li[i][j] : 0.0;
-                Fo[6 * i + j] = lij;
-                v += lij * r[j];
-                double t = 0.0;
-    #pragma unroll
-                for (int k = 0; k <= i; ++k) t += Li[i][k] * S[k][j];
-                FS[i][j] = t;
-            }
-            bo[i] = v;
+    if (f.F == nullptr) return;
+    double* Fo = const_cast<double*>(f.F) + NN * (size_t)c;
+    double* bo = const_cast<double*>(f.bhat) + ND * (size_t)c;
+    double* Ho = const_cast<double*>(f.Shat) + NN * (size_t)d.bsr_diag[c];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        double v = 0.0;
+        double fs[ND];                // row i of F S
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const double lij = j <= i ? Li[i][j] : 0.0;
+            Fo[ND * i + j] = lij;
+            v += lij * r[j];
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) t += Li[i][k] * S[k][j];
+            fs[j] = t;
         }
-        double* Ho = const_cast<double*>(f.Shat) + 36 * (size_t)d.bsr_diag[c];
-    #pragma unroll
-        for (int i = 0; i < 6; ++i)
-    #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                double v = 0.0;
-    #pragma unroll
-                for (int l = 0; l <= j; ++l) v += FS[i][l] * Li[j][l];
-                Ho[6 * i + j] = v;
-            }
+        bo[i] = v;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            double h = 0.0;
+#pragma unroll
+            for (int l = 0; l <= j; ++l) h += fs[l] * Li[j][l];
+            Ho[ND * i + j] = h;
+        }
     }
 }
 
@@ -274,23 +270,21 @@ __global__ __launch_bounds__(kBlock) void k_finish_offdiag(Dev d, FusedPcg f) {
     const double v = -d.Bsum[t];
     d.Sfull[pos] = v;
     d.Sfull[pos_t] = v;
-    if constexpr (ND == 6) {
-        if (f.F == nullptr) return;
-        const double* Fi = f.F + 36 * (size_t)r + 6 * i;
-        const double* Fj = f.F + 36 * (size_t)c + 6 * j;
-        const double* B = d.Bsum + 36 * (size_t)u;
-        double s = 0.0;
+    if (f.F == nullptr) return;
+    const double* Fi = f.F + NN * (size_t)r + ND * i;
+    const double* Fj = f.F + NN * (size_t)c + ND * j;
+    const double* B = d.Bsum + NN * (size_t)u;
+    double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            double tk = 0.0;
+    for (int k = 0; k < ND; ++k) {
+        double tk = 0.0;
 #pragma unroll
-            for (int l = 0; l < 6; ++l) tk += B[6 * k + l] * Fj[l];
-            s += Fi[k] * tk;
-        }
-        double* H = const_cast<double*>(f.Shat);
-        H[pos] = -s;
-        H[pos_t] = -s;
+        for (int l = 0; l < ND; ++l) tk += B[ND * k + l] * Fj[l];
+        s += Fi[k] * tk;
     }
+    double* H = const_cast<double*>(f.Shat);
+    H[pos] = -s;
+    H[pos_t] = -s;
 }
 
 // y = S x on the block-CSR matrix, one thread per (camera, row of the block); 42 (28) cameras per
