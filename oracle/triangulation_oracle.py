@@ -59,6 +59,10 @@ def triangulate_points(K, t1, R1, t2, R2, x1, x2):
     P1, P2 = projection(K, R1, t1), projection(K, R2, t2)
     X = triangulate(P1, P2, x1, x2)
     if reprojection_errors(P1, X, x1).mean() < 55 and reprojection_errors(P2, X, x2).mean() < 55:
+        # cv.triangulatePoints creates its output in the type of projPoints1 (the arithmetic is
+        # double either way); float32 keypoints therefore give float32 points
+        if np.asarray(x1).dtype == np.float32:
+            X = X.astype(np.float32)
         return X.reshape(-1, 1, 3)
     return None
 

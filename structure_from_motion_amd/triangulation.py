@@ -46,6 +46,10 @@ def triangulate_points(K, t1, R1, t2, R2, x1, x2, print_error=False):
     if print_error:
         print(np.mean(error1), np.mean(error2))
     if np.mean(error1) < 55 and np.mean(error2) < 55:
+        # cv.triangulatePoints hands the points back in the type of the keypoints it was given
+        # (computed in double either way); the error test above uses the unrounded points
+        if np.asarray(x1).dtype == np.float32:
+            X = X.astype(np.float32)
         return X.reshape(-1, 1, 3)
     return None
 

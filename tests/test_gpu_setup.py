@@ -109,3 +109,24 @@ def test_no_observations():
     p = syn.make_problem(4, 50, 150, seed=1, window=4)
     empty = dict(p, camera_indices=p["camera_indices"][:0], point_indices=p["point_indices"][:0], points_2d=p["points_2d"][:0])
     compare_paths(empty, solve=False)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_structures(seed):
+    # arbitrary index arrays over a valid scene: heavy and empty cameras, tracks of one to a hundred
+    # observations, duplicates, unobserved points, any order
+    rng = np.random.default_rng(100 + seed)
+    n_cam, n_pts = int(rng.integers(1, 31)), int(rng.integers(1, 201))
+    base = syn.make_problem(max(n_cam, 4), max(n_pts, 8), 2 * max(n_pts, 8), seed=seed, window=3)
+    n_obs = int(rng.integers(1, 1501))
+    cam_w = rng.random(n_cam) ** 3 + (rng.random(n_cam) < 0.8) * 1e-9
+    pt_w = rng.random(n_pts) ** 6 + (rng.random(n_pts) < 0.9) * 1e-9
+    p = dict(camera_params=base["camera_params"][:n_cam], points_3d=base["points_3d"][:n_pts], K=base["K"],
+             camera_indices=rng.choice(n_cam, n_obs, p=cam_w / cam_w.sum()).astype(np.int64),
+             point_indices=rng.choice(n_pts, n_obs, p=pt_w / pt_w.sum()).astype(np.int64),
+             points_2d=rng.uniform(0.0, 3000.0, (n_obs, 2)))
+    compare_paths(p, solve=False, schur_mode=2)
+    compare_paths(p, solve=False, schur_mode=1)
+    if seed % 3 == 0:
+        for r in range(2):
+            compare_paths(p, solve=False, schur_mode=2, rank=r, nranks=2)

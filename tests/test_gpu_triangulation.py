@@ -44,6 +44,13 @@ def test_dropin_triangulate_points_conventions():
     # the reference also accepts the (N, 1, 2)-shaped arrays OpenCV hands around
     X2 = tri.triangulate_points(*args, p["x1"].reshape(-1, 1, 2), p["x2"].reshape(-1, 1, 2))
     assert np.array_equal(X2, X)
+    # float32 keypoints (what a feature detector hands over) give float32 points, as OpenCV's
+    # output takes the type of its input points
+    x1f, x2f = p["x1"].astype(np.float32), p["x2"].astype(np.float32)
+    X3 = tri.triangulate_points(*args, x1f, x2f)
+    want3 = to.triangulate_points(*args, x1f, x2f)
+    assert X3.dtype == np.float32 and want3.dtype == np.float32 and X.dtype == np.float64
+    assert np.abs(X3 - want3).max() <= 1e-6
 
 
 def test_dropin_calculate_reprojection_error():
