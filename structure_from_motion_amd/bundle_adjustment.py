@@ -14,6 +14,7 @@ from __future__ import annotations
 import atexit
 import hashlib
 import logging
+from itertools import chain
 import time
 
 import numpy as np
@@ -182,18 +183,25 @@ class BundleAdjustment:
         corr = self.correspondences
         n_rows = len(corr)
         if n_rows:
-            # both columns hold one 2-element list per row; no Python-level loop over the rows
-            view_ids = np.array(corr["ViewId"].tolist(), dtype=object).reshape(n_rows, -1)[:, :2].ravel()
-            idx = pd.Series(view_ids).map(self.view_idx)
-            if idx.isna().any():
-                raise KeyError(view_ids[int(np.flatnonzero(idx.isna().to_numpy())[0])])
-            self.camera_indices = idx.to_numpy(dtype=np.int64)
-            feats = corr["FeatureIndex"].tolist()
-            try:
-                xy = np.asarray(feats, dtype=np.float64)                    # (rows, >= 2, 2)
-                self.points_2d = np.ascontiguousarray(xy[:, :2]).reshape(2 * n_rows, -1)
-            except ValueError:                                              # ragged rows
-                self.points_2d = np.array([np.asarray(f[k], dtype=np.float64) for f in feats for k in (0, 1)])
+            # both columns hold one 2-element list per row; the rows are flattened by the
+            # interpreter's own iterators, there is no Python-level loop over them
+            ids, feats = corr["ViewId"].tolist(), corr["FeatureIndex"].tolist()
+            if all(map((2).__eq__, map(len, ids))) and all(map((2).__eq__, map(len, feats))):
+                # (an unknown id raises KeyError, as the reference's dictionary look-up does)
+                self.camera_indices = np.fromiter(map(self.view_idx.__getitem__, chain.from_iterable(ids)),
+                                                  dtype=np.int64, count=2 * n_rows)
+                self.points_2d = np.array(list(chain.from_iterable(feats)), dtype=np.float64).reshape(2 * n_rows, -1)
+            else:                                                           # longer rows: the first two entries count
+                view_ids = np.array(ids, dtype=object).reshape(n_rows, -1)[:, :2].ravel()
+                idx = pd.Series(view_ids).map(self.view_idx)
+                if idx.isna().any():
+                    raise KeyError(view_ids[int(np.flatnonzero(idx.isna().to_numpy())[0])])
+                self.camera_indices = idx.to_numpy(dtype=np.int64)
+                try:
+                    xy = np.asarray(feats, dtype=np.float64)                # (rows, >= 2, 2)
+                    self.points_2d = np.ascontiguousarray(xy[:, :2]).reshape(2 * n_rows, -1)
+                except ValueError:                                          # ragged rows
+                    self.points_2d = np.array([np.asarray(f[k], dtype=np.float64) for f in feats for k in (0, 1)])
             self.point_indices = np.repeat(np.asarray(corr.index), 2)
         else:
             self.camera_indices = np.array([])

@@ -54,6 +54,27 @@ def test_view2idx_matches_reference_loops(tmp_path, monkeypatch):
         assert np.array_equal(z["points_2d"], p2d)
 
 
+def test_view2idx_rows_with_more_than_two_entries_and_unknown_ids(tmp_path, monkeypatch):
+    # a correspondence that names a third view (the reference's redundant-view rows): the first
+    # two entries count, as in the reference's loops; an id no view carries is a KeyError there
+    monkeypatch.chdir(tmp_path)
+    p = syn.make_problem(5, 40, 80, seed=5, window=5)
+    views = [FakeView(f"id{j}", p["camera_params"][j, :9].reshape(3, 3), p["camera_params"][j, 9:]) for j in range(5)]
+    ci = p["camera_indices"].reshape(-1, 2)
+    uv = p["points_2d"].reshape(-1, 2, 2)
+    corr = pd.DataFrame({"ViewId": [[f"id{a}", f"id{b}", "id0"] for a, b in ci],
+                         "FeatureIndex": [[uv[i, 0], uv[i, 1], uv[i, 0] + 1.0] for i in range(len(ci))]})
+    b = ba.BundleAdjustment(FakeWorldPoints(p["points_3d"], corr), p["K"], np.zeros((1, 5)), views)
+    b.view2idx()
+    cp, cidx, pidx, p2d, vidx = _reference_view2idx(views, corr)
+    assert np.array_equal(b.camera_indices, cidx) and np.array_equal(b.points_2d, p2d) and np.array_equal(b.point_indices, pidx)
+    for width in (2, 3):
+        bad = pd.DataFrame({"ViewId": [r[:width] for r in corr["ViewId"]], "FeatureIndex": [r[:width] for r in corr["FeatureIndex"]]})
+        bad.at[7, "ViewId"] = ["id1", "nobody", "id0"][:width]
+        with pytest.raises(KeyError):
+            ba.BundleAdjustment(FakeWorldPoints(p["points_3d"], bad), p["K"], np.zeros((1, 5)), views).view2idx()
+
+
 def test_sparsity_mirror_equals_oracle():
     p = syn.make_problem(4, 30, 90, seed=6, window=4)
     A = ba.bundle_adjustment_sparsity(p["n_cameras"], p["n_points"], p["camera_indices"], p["point_indices"])
