@@ -192,7 +192,9 @@ int sfmba_set_problem(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int6
  * keeps correspondences on the GPU): camera_indices, point_indices (int64) and points_2d
  * (n_obs x 2 doubles) are DEVICE pointers on the handle's GPU in the same layout; camera_params,
  * points_3d and K stay host pointers (they are small).  The arrays are only read, and only until
- * the call returns.  No counterpart in the reference, whose arrays are NumPy arrays
+ * the call returns.  A pointer the GPU cannot dereference (ordinary host memory, memory of another
+ * GPU) is refused with SFMBA_ERR_INVALID_ARGUMENT; pinned host memory and managed memory are
+ * taken.  No counterpart in the reference, whose arrays are NumPy arrays
  * (bundle_adjustment.py:117-122). */
 int sfmba_set_problem_device(sfmba_handle* h, int64_t n_cameras, int64_t n_points, int64_t n_obs,
                              const double* camera_params, const double* points_3d,

@@ -1592,9 +1592,32 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
 
 // The same with the observations already in device memory (reference layout: int64 indices,
 // n_obs x 2 doubles); cameras and points are small and still come from the host.
+// A pointer the kernels of this handle may dereference: device memory of the handle's GPU, managed
+// memory, or pinned host memory.  Anything else (an ordinary host array passed by mistake) is
+// refused here: a kernel that touched it would fault the GPU.
+void require_device_pointer(H* h, const void* ptr, const char* what) {
+    hipPointerAttribute_t attr{};
+    const hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem_device: %s is not a device pointer (%s)", what, hipGetErrorString(e));
+    }
+    if (attr.type == hipMemoryTypeDevice && attr.device != h->device)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem_device: %s lives on GPU %d, the handle on GPU %d", what, attr.device, h->device);
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeHost)
+        fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem_device: %s is not a device pointer", what);
+}
+
 void do_set_problem_device(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const double* camera_params,
                            const double* points_3d, const int64_t* cam_idx_dev, const int64_t* pt_idx_dev,
                            const double* points_2d_dev, const double* K) {
+    if (n_obs > 0) {
+        if (!cam_idx_dev || !pt_idx_dev || !points_2d_dev) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_set_problem_device: null array");
+        HIP_TRY(hipSetDevice(h->device));
+        require_device_pointer(h, cam_idx_dev, "camera_indices");
+        require_device_pointer(h, pt_idx_dev, "point_indices");
+        require_device_pointer(h, points_2d_dev, "points_2d");
+    }
     begin_problem(h, n_cam, n_pts, n_obs, camera_params, points_3d, cam_idx_dev, pt_idx_dev, points_2d_dev, K);
     SetupTrace tr;
     device_setup(h, cam_idx_dev, pt_idx_dev);

@@ -130,3 +130,19 @@ def test_random_structures(seed):
     if seed % 3 == 0:
         for r in range(2):
             compare_paths(p, solve=False, schur_mode=2, rank=r, nranks=2)
+
+
+def test_host_tensors_are_refused_where_device_pointers_are_expected():
+    # a CPU tensor handed to the device-input entry point must come back as an error, not reach a kernel
+    import torch
+    p = syn.make_problem(9, 200, 700, seed=6)
+    ci, pi, uv = (torch.from_numpy(p[k]) for k in ("camera_indices", "point_indices", "points_2d"))
+    with E.Engine() as eng:
+        with pytest.raises(E.EngineError) as e:
+            eng.set_problem_device(p["camera_params"], p["points_3d"], ci, pi.cuda(), uv.cuda(), p["K"])
+        assert "camera_indices" in str(e.value) and "device pointer" in str(e.value)
+        with pytest.raises(E.EngineError):
+            eng.set_problem_device(p["camera_params"], p["points_3d"], ci.cuda(), pi.cuda(), uv, p["K"])
+        # pinned host memory is device-accessible and is taken
+        eng.set_problem_device(p["camera_params"], p["points_3d"], ci.pin_memory(), pi.cuda(), uv.cuda(), p["K"])
+        assert eng.solve().status > 0
