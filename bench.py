@@ -227,8 +227,8 @@ def main():
     if ps.pcg_single_launch:
         # single-launch PCG: the matrix lives in registers; one iteration moves the 18-word
         # record of every gathered column and of every row written (through memory, past L2)
-        # (pipelined kernel: the 6-word w record instead)
-        rec = 48 if ps.pcg_pipelined else 144
+        # (pipelined kernel: the w record instead, one word per tangent number)
+        rec = 8 * (9 if bal else 6) if ps.pcg_pipelined else 144
         ab["bsr"] = rec * ps.schur_blocks + rec * p["n_cameras"]
     else:
         cd = 9 if bal else 6
