@@ -12,9 +12,10 @@ for case in sys.argv[3:]:
     shape, scale, seed = case.split(":")
     p = syn.make_shape(shape, seed=int(seed), scale=float(scale))
     for v in values:
-        eng = Engine(**{option: float(v)}, verbose=int(os.environ.get("VERBOSE", "0")))
+        eng = Engine(**{option: float(v) if '.' in v or 'e' in v else int(v)}, verbose=int(os.environ.get("VERBOSE", "0")))
         for rep in range(2):        # the second solve is the warm one
             eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
             st = eng.solve()
-        print(case, option, v, "iterations", st.iterations, "pcg", st.pcg_iterations, "cost", repr(st.final_cost),
+        print(case, option, v, "iterations", st.iterations, "pcg", st.pcg_iterations, "coarse solves", st.pcg_coarse_solves,
+              "dim", st.pcg_coarse_dim, "cost", repr(st.final_cost),
               "status", st.status, "optimality %.3g" % st.optimality, "ms %.3f" % (st.solve_seconds * 1e3), flush=True)

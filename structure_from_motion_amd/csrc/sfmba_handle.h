@@ -180,6 +180,16 @@ struct HandleData {
     DBuf<int> cl_ptr, cam_cl, cpair_i, cpair_j, cpair_cptr, cchunk_beg, cpair_blk, cpair_row;
     DBuf<double> cZ, cE[2], cscale, crc, cpart;
     Coarse coarse{};
+    // the same coarse space inside the single-launch PCG (k_pcg_pipe2): the operator is set up on
+    // copy_stream after a solve that took fused_coarse_from iterations or more and used by the
+    // solves after it
+    bool fused_coarse_ok = false;     // structure and sizes admit it
+    bool fused_coarse_ready = false;  // an operator has been set up (or is being set up) in this sfmba_solve
+    int fused_coarse_from = 12;
+    const double* fused_einv = nullptr;
+    bool fused_coarse_wanted = false; // set up an operator beside the next linearisation
+    DBuf<int> wg_cl;
+    hipEvent_t ev_c_assembled = nullptr, ev_c_done = nullptr;
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
     bool dense_allowed = false;  // small enough for the dense fallback
@@ -210,6 +220,8 @@ struct HandleData {
         for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
         if (pcg_host) (void)hipHostFree(pcg_host);
         if (scalars_host) (void)hipHostFree(scalars_host);
+        if (ev_c_assembled) (void)hipEventDestroy(ev_c_assembled);
+        if (ev_c_done) (void)hipEventDestroy(ev_c_done);
         if (comm && comm_destroy) comm_destroy(comm);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);

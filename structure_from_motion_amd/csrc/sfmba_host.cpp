@@ -307,11 +307,48 @@ void reduce_scalars(H* h, int first, int count) {
 // `defer`: nobody on the device needs the scalar slots of this linearisation and the host will read
 // them only with those of the trial step that follows: they are finished by that step's launch
 // (phase_trial) instead of two small launches of their own.
+// The coarse operator of the single-launch PCG is set up on copy_stream beside the kernels of the
+// next linearisation.  It reads the cameras, UG and the reduced matrix only up to the event
+// ev_c_assembled: whatever overwrites those on the main stream waits for that event first (it has
+// long passed by then), and the PCG launch that uses the operator waits for ev_c_done.
+void wait_coarse_inputs(H* h) {
+    if (h->fused_coarse_ready) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_assembled, 0));
+}
+void start_fused_coarse(H* h) {
+    if (!h->ev_c_done) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_c_assembled, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_c_done, hipEventDisableTiming));
+    }
+    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    // (the caller has waited for the main stream: the matrix of the solve just finished is in
+    // place and no single-launch solve that could still read the last operator is running)
+    h->fused_einv = launch_coarse_setup(h->dev, h->coarse, h->copy_stream, h->ev_c_assembled);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_c_done, h->copy_stream));
+    h->fused_coarse_ready = true;
+}
+// Fills the coarse fields of the launch arguments; with an operator at hand the launch waits for it.
+void arm_fused_coarse(H* h, FusedPcg& f) {
+    f.coarse = 0;
+    if (!(h->fused_coarse_ok && h->fused_coarse_ready)) return;
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_done, 0));
+    f.coarse = 1;
+    f.c_n = h->coarse.n; f.c_npad = h->coarse.n_pad;
+    f.cam_cl = h->coarse.cam_cl; f.cl_ptr = h->coarse.cl_ptr;
+    f.c_z = h->coarse.Z; f.c_einv = h->fused_einv; f.c_scale = h->coarse.scale;
+    f.wg_cl = h->wg_cl.p;
+}
+
 void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false, bool defer = false) {
     Scope t(h, F_LIN);
     refresh_dev(h);
     defer = defer && !h->has_comm();
     launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only, /*keep_v=*/false, defer);
+    // (the set-up is queued on its stream after the point-major pass is on its way: the host time
+    // of its launches falls into that kernel's run)
+    if (h->fused_coarse_wanted && !grad_only) start_fused_coarse(h);
+    h->fused_coarse_wanted = false;
+    wait_coarse_inputs(h);
     h->lin_owed = defer;
     h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
     h->have_v = !grad_only && !(lambda > 0.0);
@@ -349,6 +386,8 @@ void damp_points(H* h, double lambda) {
 // Damp with lambda: Vinv, V*^-1 g_p, block-Jacobi blocks, reduced right-hand side; in explicit
 // mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
+    if (h->fused_coarse_wanted) { start_fused_coarse(h); h->fused_coarse_wanted = false; }   // (after a rejected step)
+    wait_coarse_inputs(h);
     if (h->explicit_schur) {
         // per camera, behind the blocks: T_c = sum W Vinv W' (its own observations: the diagonal
         // block's share) and sum W Vinv g_p (the point part of the right-hand side)
@@ -427,6 +466,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         // recurrence or a barrier timeout falls through to the launch-per-iteration solver
         FusedPcg& f = h->fused;
         f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = max_iter; f.flag_slot = nullptr; f.flag_host = nullptr;
+        arm_fused_coarse(h, f);
         hipError_t e = hipErrorNotSupported;
         if (!h->fused_refused) {
             Scope t(h, F_BSR);
@@ -458,7 +498,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         }
         if (h->trace_pcg && e == hipSuccess)
             fprintf(stderr, "pcg single launch: %d iterations, %.2f us in kernel, flag %d\n", st.iter, st.ticks * 0.01, st.pad);
-        if (st.pad == 0) { h->fused_solves++; return st; }
+        if (st.pad == 0) { h->fused_solves++; if (f.coarse) h->coarse_solves++; return st; }
         h->fused_fallbacks++;
     }
     // two-level preconditioner: the coarse matrix belongs to one damping of one linearisation
@@ -590,6 +630,7 @@ bool launch_linear_solve_async(H* h) {
     f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     f.flag_slot = h->scalars.p + SLOT_PCGFLAG;
     f.flag_host = h->has_comm() ? nullptr : h->scalars_host + SLOT_PCGFLAG;
+    arm_fused_coarse(h, f);
     hipError_t e = hipErrorNotSupported;
     if (!h->fused_refused) {
         Scope t(h, F_BSR);
@@ -676,6 +717,7 @@ void do_solve(H* h, sfmba_stats* out) {
     h->fused_solves = h->fused_fallbacks = 0;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->coarse_on = h->coarse_forced; h->coarse_failed = false; h->coarse_solves = 0;
+    h->fused_coarse_ready = false; h->fused_coarse_wanted = false;
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
     auto t0 = std::chrono::steady_clock::now();
@@ -725,7 +767,11 @@ void do_solve(H* h, sfmba_stats* out) {
             const bool converged = !(ps.rz > ps.tol2 * ps.rz0);
             if (!failed && (converged || !h->dense_allowed)) {
                 h->fused_solves++;
+                if (h->fused.coarse) h->coarse_solves++;
                 st.pcg_iterations += ps.iter;
+                // a long solve: the ones after it get the coarse correction, set up from this
+                // solve's matrix while the next linearisation runs
+                if (h->fused_coarse_ok && h->fused_pcg && ps.iter >= h->fused_coarse_from) h->fused_coarse_wanted = true;
             } else {
                 // breakdown, timeout, or out of iterations with the factorisation at hand: solve
                 // again launch by launch (which knows the dense fallback) and redo the trial step
@@ -1244,7 +1290,10 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     // (a single cluster would span the gauge directions of the whole problem and nothing else: S
     // vanishes on them up to the damping, the coarse matrix is rounding noise and the iteration
     // gains nothing; at least two clusters are required)
-    if (coarse >= 0 && !want_dense && !h->fused_pcg && (coarse > 0 || n_cam >= 256) && n_cam / coarse_k >= 2) {
+    h->fused_coarse_ok = false;
+    h->fused_coarse_ready = false;
+    h->fused_coarse_wanted = false;
+    if (coarse >= 0 && !want_dense && (coarse > 0 || n_cam >= 256) && n_cam / coarse_k >= 2) {
         const int k = coarse_k;
         const int n_cl = n_cam / k;
         std::vector<int> cl_ptr((size_t)n_cl + 1), cam_cl((size_t)n_cam);
@@ -1303,7 +1352,41 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         h->coarse_built = true;
         h->coarse_from = kCoarseFromIterations;
         h->coarse_forced = coarse > 0;
-        if (const char* e = getenv("SFMBA_PCG_COARSE_FROM")) {     // tuning: the switch-on rule with any cluster size
+        if (h->fused_pcg) {
+            // the same space inside the single launch (k_pcg_pipe2), where its limits hold:
+            // 6 x 6 blocks, the pipelined form, at most 256 workgroups of 8 rows, clusters of at
+            // least 8 cameras spread over at most 7 workgroups, at most 288 coarse unknowns after
+            // padding, at most 4 clusters among the columns of the rows of one workgroup
+            const int rows = pcg_fused_rows_per_block();
+            bool ok = h->cd == 6 && h->fused.pipelined && h->fused_blocks <= 256 && k7.n_pad <= 288 && k >= rows;
+            for (int i = 0; ok && i < n_cl; ++i) ok = (cl_ptr[i + 1] - 1) / rows - cl_ptr[i] / rows + 1 <= 7;
+            std::vector<int> wg_cl((size_t)5 * std::max(h->fused_blocks, 1), 0);
+            for (int b = 0; ok && b * rows < n_cam && b < h->fused_blocks; ++b) {
+                int* list = &wg_cl[(size_t)5 * b + 1];
+                int n = 0;
+                for (int r = b * rows; ok && r < std::min(n_cam, (b + 1) * rows); ++r)
+                    for (int e = bsr_ptr[r]; ok && e < bsr_ptr[r + 1]; ++e) {
+                        const int J = cam_cl[bsr_col[e]];
+                        bool seen = false;
+                        for (int q = 0; q < n; ++q) seen = seen || list[q] == J;
+                        if (!seen) { if (n < 4) list[n++] = J; else ok = false; }
+                    }
+                wg_cl[(size_t)5 * b] = n;
+            }
+            if (ok) {
+                h->wg_cl.upload(wg_cl, st);
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            if (const char* e = getenv("SFMBA_PCG_FUSED_COARSE")) ok = ok && atoi(e) != 0;
+            h->fused_coarse_ok = ok;
+            h->fused_coarse_from = 12;
+            if (const char* e = getenv("SFMBA_PCG_FUSED_COARSE_FROM")) h->fused_coarse_from = std::max(1, atoi(e));
+            // the launch-per-iteration solver, which a failed single launch falls back to, stays
+            // block-Jacobi: its own use of these buffers would collide with the set-up on the side stream
+            h->coarse_forced = false;
+            h->coarse_from = 1 << 30;
+        }
+        if (const char* e = h->fused_pcg ? nullptr : getenv("SFMBA_PCG_COARSE_FROM")) {     // tuning: the switch-on rule with any cluster size
             h->coarse_from = std::max(1, atoi(e));
             h->coarse_forced = false;
         }

@@ -66,9 +66,20 @@ struct FusedPcg {
     long long admit_ticks;    // the first poll (all workgroups resident and started)
     int blocks;               // workgroups of the launch
     int pipelined;            // 1: k_pcg_pipe (reduction overlapped with the product), 0: k_pcg_fused
+    // two-level preconditioner inside the launch (k_pcg_pipe2): the coarse operator of sfmba_coarse.hip
+    int coarse;               // 1: use it
+    int c_n, c_npad;          // coarse unknowns, padded
+    const int* cam_cl;        // [n_cam] cluster of each camera
+    const int* cl_ptr;        // [clusters + 1] camera range of each cluster
+    const int* wg_cl;         // [blocks][5] per workgroup: count, then the clusters among the columns of its rows
+    const double* c_z;        // [n_cam][7][6] coarse basis
+    const double* c_einv;     // [c_npad][c_npad] (D E D)^-1
+    const double* c_scale;    // [c_npad] D
 };
 constexpr int kPcgSlots = 4;      // rotating generation slots of the single-launch PCG
 constexpr int kPcgVecRec = 18;    // r[6] w[6] s[6] of one camera and generation
+constexpr int kPcgRecWords = 16;  // words reserved per workgroup and generation for its record of global
+                                  // sums (k_pcg_fused and k_pcg_pipe use the first two)
 
 // Everything a kernel needs, passed by value.  "pm" arrays are in point-major observation
 // order (observations of one point contiguous), "cm" arrays in camera-major order.
@@ -225,7 +236,7 @@ void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_coarse.hip
-const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st);    // returns the buffer holding the inverse
+const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled = nullptr);    // returns the buffer holding the inverse
 void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st);  // pz += Z E^-1 Z' pr, r'z partials
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)
 void launch_triangulate(const double* P1, const double* P2, int n, const double2* x1, const double2* x2,

@@ -992,6 +992,433 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
     }
 }
 
+// ---- the pipelined solve with the two-level preconditioner inside the launch ---------------
+// Block-Jacobi leaves the modes that move whole groups of cameras together (sfmba_coarse.hip);
+// the last linear solves of a run spend nine tenths of their iterations on them.  Here the
+// additive coarse correction M^-1 = M_J^-1 + Z C Z' (C = D Einv D of a coarse operator the host
+// hands over: the one of the LM iteration before, set up beside the other kernels) runs inside the
+// single launch.  In the scaled variables the block-Jacobi part is the identity and
+// Mhat^-1 = I + Zhat C Zhat' with Zhat_c = F_c^-T Z_c.  Preconditioned pipelined CG:
+//     gamma = r'u, delta = w'u                         (published, summed by everybody later)
+//     m = Mhat^-1 w = w + Zhat y,  y = C Zhat' w
+//     n = Shat m = Shat w + G y,   G_r = sum_c Shat_rc Zhat_c per cluster of the row's columns
+//     beta = gamma / gamma_prev;  alpha = gamma / (delta - beta gamma / alpha_prev)
+//     z = n + beta z; q = m + beta q; s = w + beta s; p = u + beta p
+//     x += alpha p; r -= alpha s; u -= alpha q; w -= alpha z
+// The 7 coarse sums of a cluster are global sums like gamma and delta and travel with them: a
+// workgroup's record has 16 words (gamma, delta, the partial sums Zhat' w of the at most two
+// clusters its eight rows lie in), published before the product; every workgroup reads all
+// records, adds them in a fixed order and multiplies the rows of C it needs (the clusters of the
+// columns of its rows, at most kC2WgCl; 18 columns of 28 rows per thread, in registers) - so the
+// coarse correction costs no further trip across the dies, only three more workgroup barriers.
+// Restrictions, checked by the host: those of k_pcg_pipe, 6 x 6 blocks, at most 256 workgroups,
+// clusters of at least 8 cameras whose rows lie in at most kC2Span workgroups, a coarse dimension of
+// at most 288 after padding, at most
+// kC2RowCl clusters among the columns of a row and kC2WgCl among those of a workgroup's rows.
+constexpr int kC2Rec = kPcgRecWords;    // words of a workgroup's record
+constexpr int kC2RowCl = 4;
+constexpr int kC2WgCl = 4;
+constexpr int kC2Cols = 18;             // columns of C per thread: n_pad <= 16 * 18
+constexpr int kC2MaxBlocks = 256;
+constexpr int kC2Span = 7;              // workgroups with rows in one cluster, at most
+
+__global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
+    constexpr int ND = 6, NV = kCoarseVecs;
+    __shared__ double red[kFusedWaves][kC2Rec];
+    __shared__ double2 dotbuf[kFusedWaves];
+    __shared__ __attribute__((aligned(16))) double tiles[kFusedWaves][64 * ND + 64];
+    __shared__ double Gl[kFusedWaves][kC2RowCl][ND][NV];
+    __shared__ double zhat[kFusedWaves][ND][NV];
+    __shared__ int rowwg[kFusedWaves][kC2RowCl], wslot[kFusedWaves];
+    __shared__ double tvec[16 * kC2Cols];
+    __shared__ double ywg[kC2WgCl * NV];
+    __shared__ double crows[kC2WgCl * NV][16 * kC2Cols + 4];     // (the 4: rows start 8 banks apart)
+    __shared__ int off_lds[kFusedWaves][ND][64];
+    __shared__ int fail_lds;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int G = gridDim.x, row = blockIdx.x * kFusedWaves + w;
+    const bool mine = row < a.n_cam;
+    const long long t_start = (long long)wall_clock64();
+    unsigned long long* drec = reinterpret_cast<unsigned long long*>(a.dots);
+    double* tile = tiles[w];
+    Poller poll;
+    poll.abort_word = drec + kC2Rec * kSlots * (size_t)G;
+    poll.deadline = t_start + a.admit_ticks;
+    const size_t gen_stride = (size_t)a.n_cam * ND;
+    if (tid == 0) fail_lds = 0;
+    for (int i = tid; i < 16 * kC2Cols; i += kFusedThreads) tvec[i] = 0.0;
+
+    // this lane's block of the row, the word offsets of the cooperative gather, the cluster of
+    // the block's column
+    int nb = 0, b0 = 0;
+    double S[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) S[i] = 0.0;
+#pragma unroll
+    for (int t = 0; t < ND; ++t) off_lds[w][t][lane] = -1;
+    int cl = -1;
+    if (mine) {
+        b0 = a.bsr_ptr[row];
+        nb = a.bsr_ptr[row + 1] - b0;
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int e = 64 * t + lane, blk = e / ND, j = e - ND * blk;
+            off_lds[w][t][lane] = blk < nb ? a.bsr_col[b0 + blk] * ND + j : -1;
+        }
+        if (lane < nb) {
+            const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)(b0 + lane));
+#pragma unroll
+            for (int i = 0; i < 18; ++i) { const double2 v = sp[i]; S[2 * i] = v.x; S[2 * i + 1] = v.y; }
+            cl = a.cam_cl[a.bsr_col[b0 + lane]];
+        }
+    }
+    // clusters among the row's columns: the columns ascend and clusters are runs of consecutive
+    // cameras, so every cluster is a run of lanes; slot = its rank in the row
+    const int cl_prev = __shfl_up(cl, 1, 64);
+    const bool is_new = lane < nb && (lane == 0 || cl != cl_prev);
+    const unsigned long long new_mask = __ballot(is_new);
+    const int slot = __popcll(new_mask & ((2ull << lane) - 1ull)) - 1;
+    const int n_rowcl = __popcll(new_mask);
+    // the clusters among the columns of this workgroup's rows: listed by the host (count, then ids)
+    const int wgcl_n = a.wg_cl[(kC2WgCl + 1) * blockIdx.x];
+    int wgcl[kC2WgCl];
+#pragma unroll
+    for (int e = 0; e < kC2WgCl; ++e) wgcl[e] = a.wg_cl[(kC2WgCl + 1) * blockIdx.x + 1 + e];
+    if (is_new && slot < kC2RowCl) {
+        int at = 0;
+#pragma unroll
+        for (int e = 0; e < kC2WgCl; ++e) if (e < wgcl_n && wgcl[e] == cl) at = e;
+        rowwg[w][slot] = at;
+    }
+    if (lane == 0) wslot[w] = mine ? a.cam_cl[row] - a.cam_cl[blockIdx.x * kFusedWaves] : -1;
+    if (tid == 0 && (G > kC2MaxBlocks || a.c_npad > 16 * kC2Cols || wgcl_n > kC2WgCl)) {
+        fail_lds = 1;
+        st_word(poll.abort_word, 0ull);
+    }
+    block_barrier();
+    int flag = fail_lds ? 2 : 0;
+
+    // the rows of C = D Einv D this workgroup needs: thread = (row of the list, column mod 16)
+    const int c_rho = tid >> 4, c_part = tid & 15;
+    const bool c_act = !flag && c_rho < NV * wgcl_n;
+    int c_grow = 0;
+    double crow_scale = 0.0;
+    if (c_act) {
+        const int ws = c_rho / NV;
+        c_grow = NV * wgcl[ws] + (c_rho - NV * ws);
+        crow_scale = a.c_scale[c_grow];
+    }
+    // the workgroups whose records hold the partial sums of cluster I (thread = (I, j)): a range,
+    // and for each of them whether the cluster is the first or the second of that workgroup
+    int tb0 = 0, tb1 = -1;
+    unsigned tsecond = 0u;
+    if (!flag && tid < a.c_n) {
+        const int I = tid / NV;
+        tb0 = a.cl_ptr[I] / kFusedWaves;
+        tb1 = (a.cl_ptr[I + 1] - 1) / kFusedWaves;
+        for (int b = tb0; b <= tb1 && b - tb0 < kC2Span; ++b)
+            if (a.cam_cl[b * kFusedWaves] != I) tsecond |= 1u << (b - tb0);
+        tb1 = min(tb1, tb0 + kC2Span - 1);      // (the host admits no longer range)
+    }
+
+    // Zhat of this row: lane j < 7 solves F_r' x = Z_r[j] (F lower triangular, so F' x = z is a back
+    // substitution) and keeps column j; lane k < 6 keeps row k
+    auto back_subst = [&](const double* __restrict__ F, const double* __restrict__ z, double (&x)[ND]) {
+#pragma unroll
+        for (int k = ND - 1; k >= 0; --k) {
+            double v = z[k];
+#pragma unroll
+            for (int l = k + 1; l < ND; ++l) v -= F[ND * l + k] * x[l];
+            x[k] = v / F[ND * k + k];
+        }
+    };
+    if (lane < NV) {
+        double zc[ND] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (!flag && mine) back_subst(a.F + 36 * (size_t)row, a.c_z + (NV * (size_t)row + lane) * ND, zc);
+#pragma unroll
+        for (int k = 0; k < ND; ++k) zhat[w][k][lane] = zc[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // own cluster's place in the workgroup's list
+    int own_ws = 0;
+    if (!flag && mine) {
+        const int J = a.cam_cl[row];
+#pragma unroll
+        for (int e = 0; e < kC2WgCl; ++e) if (e < wgcl_n && wgcl[e] == J) own_ws = e;
+    }
+
+    double o_r = 0.0, o_u = 0.0, o_w = 0.0, o_z = 0.0, o_q = 0.0, o_s = 0.0, o_p = 0.0, o_x = 0.0;
+
+    // tau_j = sum_k Zhat[k][j] v_k for the vector whose component k lane k < 6 holds (lanes j < 7)
+    auto restrict_row = [&](double vk) -> double {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ND) tile[lane] = vk;
+        __builtin_amdgcn_wave_barrier();
+        double t = 0.0;
+        if (lane < NV) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) t = fma(zhat[w][k][lane], tile[k], t);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return t;
+    };
+    // the record of generation gen: gamma and delta summed over the workgroup's rows, the coarse
+    // partial sums per cluster of the workgroup
+    auto publish = [&](double g, double dl, double tau, int gen) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ND) reinterpret_cast<double2*>(tile)[lane] = make_double2(g, dl);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double sg = 0.0, sd = 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) { const double2 v = reinterpret_cast<const double2*>(tile)[i]; sg += v.x; sd += v.y; }
+            red[w][0] = sg; red[w][1] = sd;
+        }
+        if (lane < NV) red[w][2 + lane] = tau;
+        block_barrier();
+        if (tid < kC2Rec) {
+            double sum = 0.0;
+            if (tid < 2) {
+                for (int v = 0; v < kFusedWaves; ++v) sum += red[v][tid];
+            } else {
+                const int sl = (tid - 2) / NV, j = (tid - 2) - NV * sl;
+                for (int v = 0; v < kFusedWaves; ++v) if (wslot[v] == sl) sum += red[v][2 + j];
+            }
+            st_word(drec + kC2Rec * ((size_t)(gen % kSlots) * G + blockIdx.x) + tid, (unsigned long long)__double_as_longlong(sum));
+        }
+    };
+    // every workgroup's record of generation gen: the dots, then y = C (sum of the coarse partials)
+    // for the clusters of this workgroup's list.  Returns false on a timeout or an abort.
+    double gam = 0.0, del = 0.0;
+    auto collect = [&](int gen, bool okw) -> bool {
+        // thread t < G reads the dots of workgroup t; thread t < c_n = (cluster I, vector j) reads
+        // its sum's term from the record of every workgroup with rows in cluster I
+        double sum_g = 0.0, sum_d = 0.0, tsum = 0.0;
+        if (okw) {
+            const unsigned long long* base = drec + kC2Rec * (size_t)(gen % kSlots) * G;
+            const bool reader = tid < G;
+            const int tj = 2 + tid % NV;
+            for (int spins = 1;; ++spins) {
+                bool ok = true;
+                if (reader) {
+                    const unsigned long long ug = ld_word(base + kC2Rec * (size_t)tid), ud = ld_word(base + kC2Rec * (size_t)tid + 1);
+                    ok = ug != kSentinel && ud != kSentinel;
+                    sum_g = __longlong_as_double((long long)ug);
+                    sum_d = __longlong_as_double((long long)ud);
+                }
+                // (all loads of a round requested before the first is looked at)
+                unsigned long long u[kC2Span];
+#pragma unroll
+                for (int q = 0; q < kC2Span; ++q)
+                    if (tb0 + q <= tb1) u[q] = ld_word(base + kC2Rec * (size_t)(tb0 + q) + tj + ((tsecond >> q) & 1u ? NV : 0));
+                tsum = 0.0;
+#pragma unroll
+                for (int q = 0; q < kC2Span; ++q)
+                    if (tb0 + q <= tb1) { ok = ok && u[q] != kSentinel; tsum += __longlong_as_double((long long)u[q]); }
+                if (__all(ok)) break;
+                if (poll.expired(spins)) { okw = false; break; }
+            }
+            if (!reader || !okw) { sum_g = 0.0; sum_d = 0.0; }
+        }
+        sum_g = wave_sum(sum_g);
+        sum_d = wave_sum(sum_d);
+        if (lane == 0) dotbuf[w] = make_double2(sum_g, sum_d);
+        if (tid < a.c_n) tvec[tid] = tsum;
+        if (!okw && lane == 0) fail_lds = 1;
+        block_barrier();
+        if (fail_lds) return false;
+        gam = 0.0; del = 0.0;
+#pragma unroll
+        for (int i = 0; i < kFusedWaves; ++i) { const double2 d2 = dotbuf[i]; gam += d2.x; del += d2.y; }
+        if (NV * wgcl_n > 4 * w) {          // this wavefront has rows of the list (four per wavefront)
+            double part = 0.0;
+            if (c_act) {
+#pragma unroll
+                for (int u = 0; u < kC2Cols; ++u) part = fma(crows[c_rho][c_part + 16 * u], tvec[c_part + 16 * u], part);
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 8, 64);
+            if (c_part == 0 && c_act) ywg[c_rho] = crow_scale * part;
+        }
+        block_barrier();
+        return true;
+    };
+    // (G y)_i of this row for lane i < 6
+    auto coarse_row = [&]() -> double {
+        double t = 0.0;
+        for (int sl = 0; sl < n_rowcl; ++sl) {
+            const double* yy = ywg + NV * rowwg[w][sl];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) t = fma(Gl[w][sl][lane][j], yy[j], t);
+        }
+        return t;
+    };
+    auto own_correction = [&]() -> double {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) t = fma(zhat[w][lane][j], ywg[NV * own_ws + j], t);
+        return t;
+    };
+
+    double gam0 = 0.0, gam_prev = 0.0, alpha_prev = 1.0;
+    int it = 0;
+    double qa0 = 0.0;
+    if (!flag) {
+        // generation 0: r0 = bhat, u0 = Mhat^-1 r0 needs the coarse sums of bhat; w0 = Shat u0 =
+        // Shat bhat + G y (bhat of the row's columns is in memory)
+        double y[ND] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (mine && lane < nb) {
+            const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b0 + lane]);
+            const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
+            const double rc[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i) y[i] = j == 0 ? S[ND * i] * rc[0] : fma(S[ND * i + j], rc[j], y[i]);
+            }
+        }
+        qa0 = row_total(y, lane, tile);
+        if (mine && lane < ND) o_r = a.bhat[ND * (size_t)row + lane];
+        const double tau = restrict_row(o_r);
+        publish(0.0, 0.0, tau, 0);
+    }
+    // (while the records of generation 0 travel)
+    // rows of C = D Einv D this workgroup needs, in LDS
+    if (c_act) {
+        const double* __restrict__ e = a.c_einv + (size_t)c_grow * a.c_npad;
+#pragma unroll
+        for (int u = 0; u < kC2Cols; ++u) {
+            const int col = c_part + 16 * u;
+            crows[c_rho][col] = col < a.c_npad ? e[col] * a.c_scale[col] : 0.0;
+        }
+    }
+    // G_r: per cluster slot of the row the sum over its lanes of Shat_rc Zhat_c, one coarse vector at a time
+    if (!flag && mine) {
+        const bool act = lane < nb;
+        const double* __restrict__ Fc = a.F + 36 * (size_t)(act ? a.bsr_col[b0 + lane] : row);
+        const double* __restrict__ Zc = a.c_z + NV * ND * (size_t)(act ? a.bsr_col[b0 + lane] : row);
+#pragma unroll 1
+        for (int j = 0; j < NV; ++j) {
+            double x[ND], P[ND];
+            back_subst(Fc, Zc + ND * j, x);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                double t = S[ND * i] * x[0];
+#pragma unroll
+                for (int k = 1; k < ND; ++k) t = fma(S[ND * i + k], x[k], t);
+                P[i] = act ? t : 0.0;
+            }
+            for (int sl = 0; sl < n_rowcl && sl < kC2RowCl; ++sl) {
+                double v[ND];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) v[i] = slot == sl ? P[i] : 0.0;
+                const double tot = row_total(v, lane, tile);
+                if (lane < ND) Gl[w][sl][lane][j] = tot;
+            }
+        }
+    }
+    if (!flag) {
+        if (!collect(0, true)) flag = 2;
+        else if (mine && lane < ND) {
+            o_u = o_r + own_correction();
+            o_w = qa0 + coarse_row();
+        }
+        poll.deadline = t_start + a.timeout_ticks;
+    }
+    while (!flag) {
+        const int gen = it + 1, slotg = gen % kSlots;
+        double* vcur = a.vec + (size_t)slotg * gen_stride;
+        // the stores of the iteration before (the re-arming among them) have landed before
+        // anything of this generation is stored
+        __builtin_amdgcn_s_waitcnt(0);
+        if (mine && lane < ND) st_shared(vcur + (size_t)row * ND + lane, o_w);
+        const double tau = restrict_row(o_w);
+        publish(o_r * o_u, o_w * o_u, tau, gen);
+        // everybody has left generation gen - 2 (its records were collected an iteration ago):
+        // re-arm this workgroup's words of that slot, which will take generation gen + 2
+        if (gen >= 2) {
+            double* arm = a.vec + (size_t)((gen - 2) % kSlots) * gen_stride;
+            if (mine && lane < ND) st_word(reinterpret_cast<unsigned long long*>(arm + (size_t)row * ND) + lane, kSentinel);
+            if (tid < kC2Rec) st_word(drec + kC2Rec * ((size_t)((gen - 2) % kSlots) * G + blockIdx.x) + tid, kSentinel);
+        }
+        // Shat w: the w of the row's columns, fetched cooperatively
+        bool okw = true;
+        for (int spins = 1;; ++spins) {
+            bool ok = true;
+            double val[ND];
+            int off[ND];
+#pragma unroll
+            for (int t = 0; t < ND; ++t) off[t] = off_lds[w][t][lane];
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+                if (off[t] >= 0) val[t] = ld_shared(vcur + off[t]);
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+                if (off[t] >= 0) { ok = ok && !is_sentinel(val[t]); tile[64 * t + lane] = val[t]; }
+            if (__all(ok)) break;
+            if (poll.expired(spins)) { okw = false; break; }
+        }
+        double y[ND] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        __builtin_amdgcn_wave_barrier();
+        if (okw && lane < nb) {
+            const double* u = tile + ND * lane;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const double wj = u[j];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) y[i] = j == 0 ? S[ND * i] * wj : fma(S[ND * i + j], wj, y[i]);
+            }
+        }
+        const double qa = row_total(y, lane, tile);
+        if (!collect(gen, okw)) { flag = 2; break; }
+        if (it == 0) {
+            gam0 = gam;
+            if (!(gam > 0.0)) break;                        // zero (or NaN) right-hand side
+        } else if (!(gam > a.tol2 * gam0) || it >= a.max_iter) {
+            break;
+        }
+        const double beta = it ? gam / gam_prev : 0.0;
+        const double den = del - (it ? beta * gam / alpha_prev : 0.0);
+        if (!(den > 0.0)) { flag = 1; break; }               // breakdown: caller falls back
+        const double alpha = gam / den;
+        gam_prev = gam;
+        alpha_prev = alpha;
+        if (mine && lane < ND) {
+            const double m = o_w + own_correction();
+            const double n = qa + coarse_row();
+            o_z = fma(beta, o_z, n);
+            o_q = fma(beta, o_q, m);
+            o_s = fma(beta, o_s, o_w);
+            o_p = fma(beta, o_p, o_u);
+            o_x = fma(alpha, o_p, o_x);
+            o_r = fma(-alpha, o_s, o_r);
+            o_u = fma(-alpha, o_q, o_u);
+            o_w = fma(-alpha, o_z, o_w);
+        }
+        ++it;
+    }
+    // x = F' xhat for the row this wavefront owns
+    if (flag != 2 && mine) {
+        double val = 0.0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const double xj = __shfl(o_x, j, 64);
+            if (lane < ND) val += a.F[36 * (size_t)row + ND * j + lane] * xj;
+        }
+        if (lane < ND) a.x[ND * (size_t)row + lane] = val;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState st;
+        st.rz = gam; st.rz0 = gam0; st.tol2 = a.tol2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
+        st.ticks = (long long)wall_clock64() - t_start;
+        *a.out = st;
+        if (a.flag_slot) *a.flag_slot = (double)flag;
+        if (a.flag_host) *a.flag_host = (double)flag;
+    }
+}
+
 int pcg_fused_max_blocks(int device) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_fused, kFusedThreads, 0) != hipSuccess) return 0;
@@ -1001,7 +1428,7 @@ int pcg_fused_max_blocks(int device) {
 }
 
 int pcg_fused_rows_per_block() { return kFusedWaves; }
-size_t pcg_fused_record_words(int blocks) { return 2 * kSlots * (size_t)blocks + 1; }
+size_t pcg_fused_record_words(int blocks) { return kPcgRecWords * kSlots * (size_t)blocks + 1; }
 size_t pcg_fused_vector_words(int n_cam) { return kSlots * (size_t)n_cam * kVecRec; }
 
 // Arms every record (all bits set) and the abort word unless that has been done, then launches
@@ -1016,7 +1443,9 @@ hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st) {
     }
     FusedPcg arg = f;
     if (f.nd != 6 && !(f.nd == 9 && f.pipelined)) return hipErrorInvalidValue;
-    if (f.pipelined && f.nd == 9) hipLaunchKernelGGL((k_pcg_pipe<9>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    if (f.coarse && (f.nd != 6 || !f.pipelined)) return hipErrorInvalidValue;
+    if (f.coarse) hipLaunchKernelGGL(k_pcg_pipe2, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    else if (f.pipelined && f.nd == 9) hipLaunchKernelGGL((k_pcg_pipe<9>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     else if (f.pipelined) hipLaunchKernelGGL((k_pcg_pipe<6>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     else hipLaunchKernelGGL(k_pcg_fused, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     return hipGetLastError();

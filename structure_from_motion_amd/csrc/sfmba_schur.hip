@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const 
         // arm the exchange buffers of the single-launch PCG: every word all bits set
         unsigned long long* vw = reinterpret_cast<unsigned long long*>(f.vec);
         unsigned long long* dw = reinterpret_cast<unsigned long long*>(f.dots);
-        const size_t nv = (size_t)kPcgSlots * d.n_cam * kPcgVecRec, nd = 2 * (size_t)kPcgSlots * f.blocks + 1;
+        const size_t nv = (size_t)kPcgSlots * d.n_cam * kPcgVecRec, nd = (size_t)kPcgRecWords * kPcgSlots * f.blocks + 1;
         const size_t t = blockIdx.x * 64 + threadIdx.x, nt = (size_t)gridDim.x * 64;
         for (size_t i = t; i < nv; i += nt) vw[i] = ~0ull;
         for (size_t i = t; i < nd; i += nt) dw[i] = ~0ull;
