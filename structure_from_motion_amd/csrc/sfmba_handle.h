@@ -188,6 +188,7 @@ struct HandleData {
     int fused_coarse_from = 12;
     const double* fused_einv = nullptr;
     bool fused_coarse_wanted = false; // set up an operator beside the next linearisation
+    double solve_rtol = 0.0;          // PCG tolerance of the sfmba_solve in progress (0 outside one)
     DBuf<int> wg_cl;
     hipEvent_t ev_c_assembled = nullptr, ev_c_done = nullptr;
     // dense Cholesky solver

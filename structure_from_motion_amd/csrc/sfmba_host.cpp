@@ -458,8 +458,20 @@ void schur_product(H* h, const double* x, const PcgState* state) {
 constexpr int kCoarseFromIterations = 24;
 
 // Block-Jacobi PCG on S dc = rhs; result in px.  Returns the iteration count.
+// The forcing term of the inexact step when the caller leaves it open.  A PCG iteration of the
+// single-launch solver costs a hundredth of an LM iteration (3 to 5 us against the passes over the
+// observations), so the linear systems are solved more accurately there: the outer iteration then
+// converges in one step less on most problems (4 instead of 5 at the Venice shape).  With a launch
+// (or two) per PCG iteration the extra iterations cost what the saved step gains.
+// Chosen once per sfmba_solve (a single launch that is refused half-way does not change it).
+double pcg_rtol_of(const H* h) {
+    if (h->opt.pcg_rtol > 0) return h->opt.pcg_rtol;
+    if (h->solve_rtol > 0) return h->solve_rtol;
+    return h->explicit_schur && h->fused_pcg && !h->use_dense ? 0.03 : 0.1;
+}
+
 PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
-    const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
+    const double tol = pcg_rtol_of(h);
     const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     if (allow_fused && h->explicit_schur && h->fused_pcg) {
         // the whole solve in one launch; a breakdown of the single-reduction
@@ -625,7 +637,7 @@ constexpr double kPcgRefused = 1024.0;
 bool launch_linear_solve_async(H* h) {
     if (!(h->explicit_schur && h->fused_pcg && !h->use_dense)) return false;
     if (h->fused_refused && !h->has_comm()) { h->fused_pcg = false; return false; }
-    const double tol = h->opt.pcg_rtol > 0 ? h->opt.pcg_rtol : 0.1;
+    const double tol = pcg_rtol_of(h);
     FusedPcg& f = h->fused;
     f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     f.flag_slot = h->scalars.p + SLOT_PCGFLAG;
@@ -718,6 +730,9 @@ void do_solve(H* h, sfmba_stats* out) {
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->coarse_on = h->coarse_forced; h->coarse_failed = false; h->coarse_solves = 0;
     h->fused_coarse_ready = false; h->fused_coarse_wanted = false;
+    h->solve_rtol = 0.0;
+    h->solve_rtol = pcg_rtol_of(h);
+    struct ClearRtol { H* h; ~ClearRtol() { h->solve_rtol = 0.0; } } clear_rtol{h};
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
     auto t0 = std::chrono::steady_clock::now();
@@ -770,8 +785,13 @@ void do_solve(H* h, sfmba_stats* out) {
                 if (h->fused.coarse) h->coarse_solves++;
                 st.pcg_iterations += ps.iter;
                 // a long solve: the ones after it get the coarse correction, set up from this
-                // solve's matrix while the next linearisation runs
-                if (h->fused_coarse_ok && h->fused_pcg && ps.iter >= h->fused_coarse_from) h->fused_coarse_wanted = true;
+                // solve's matrix while the next linearisation runs.  The operator stays in use for
+                // the rest of the run (the reduced matrix of the later iterations differs little
+                // from this one: measured, the operator of the iteration before preconditions as
+                // well as the current one) and is renewed when a solve with it grows long again.
+                if (h->fused_coarse_ok && h->fused_pcg &&
+                    ps.iter >= (h->fused.coarse ? 4 * h->fused_coarse_from : h->fused_coarse_from))
+                    h->fused_coarse_wanted = true;
             } else {
                 // breakdown, timeout, or out of iterations with the factorisation at hand: solve
                 // again launch by launch (which knows the dense fallback) and redo the trial step
@@ -1764,7 +1784,7 @@ void sfmba_default_options(sfmba_options* o) {
     if (!o) return;
     memset(o, 0, sizeof *o);
     o->ftol = 1e-4; o->xtol = 1e-12; o->gtol = 1e-8; o->max_nfev = 0;
-    o->max_iterations = 200; o->initial_lambda = 1e-4; o->pcg_rtol = 0.1; o->pcg_max_iter = 1000;
+    o->max_iterations = 200; o->initial_lambda = 1e-4; o->pcg_rtol = 0.0; o->pcg_max_iter = 1000;
     o->linear_solver = SFMBA_SOLVER_AUTO; o->dense_max_dim = 1536; o->verbose = 0; o->profile = 0; o->device = -1;
     o->rank = 0; o->nranks = 1;
     o->pcg_mode = 0; o->pcg_blocks = 0;

@@ -315,7 +315,7 @@ def test_single_launch_and_stepwise_pcg_take_the_same_iterations():
     g = load_golden("bal_shuffled_9_200_700")
     out = {}
     for mode in (1, 2):
-        with make_engine(g, linear_solver=1, schur_mode=2, pcg_mode=mode, pcg_coarse=-1) as eng:
+        with make_engine(g, linear_solver=1, schur_mode=2, pcg_mode=mode, pcg_coarse=-1, pcg_rtol=0.1) as eng:
             st = eng.solve()
             out[mode] = (st, eng.get_params())
     a, b2 = out[1][0], out[2][0]

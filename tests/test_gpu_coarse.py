@@ -1,4 +1,5 @@
-"""GPU: the two-level preconditioner of the launch-per-iteration PCG (options.pcg_coarse).
+"""GPU: the two-level preconditioner of the launch-per-iteration PCG (options.pcg_coarse) and of
+the single-launch PCG.
 
 No counterpart in the reference (its LSMR runs unpreconditioned, scipy/optimize/_lsq/trf.py:479);
 the checks are against NumPy algebra on the matrices the engine hands out, and against the
@@ -163,3 +164,44 @@ def test_a_single_cluster_is_not_built():
     with _engine(p, "pinhole", pcg_coarse=48) as eng:      # 80 // 48 = 1 cluster: the global gauge only
         st = eng.solve()
     assert st.pcg_coarse_dim == 0 and st.pcg_coarse_solves == 0
+
+
+# ---- the same coarse space inside the single-launch PCG ------------------------------------
+
+def _solve_single_launch(p, monkeypatch, coarse, **opts):
+    monkeypatch.setenv("SFMBA_PCG_FUSED_COARSE", "1" if coarse else "0")
+    with _engine(p, "pinhole", pcg_mode=2, **opts) as eng:
+        first = eng.solve()
+        params = eng.get_params()
+        eng.reset_params()
+        second = eng.solve()
+    return first, second, params
+
+
+@pytest.mark.parametrize("n_cam", [300, 700])
+def test_single_launch_pcg_with_the_coarse_correction(monkeypatch, n_cam):
+    # long camera chains: block-Jacobi needs many iterations late in the run; the coarse operator is
+    # set up after the first long solve and used by the solves after it, inside the one launch
+    p = syn.make_problem(n_cam, 25 * n_cam, 130 * n_cam, seed=21)
+    plain, _, (cams0, pts0) = _solve_single_launch(p, monkeypatch, False, ftol=1e-10, pcg_rtol=0.03)
+    st, again, (cams1, pts1) = _solve_single_launch(p, monkeypatch, True, ftol=1e-10, pcg_rtol=0.03)
+    assert plain.pcg_coarse_solves == 0 and st.pcg_coarse_solves > 0
+    assert st.pcg_single_launch == st.iterations and st.pcg_single_fallbacks == 0 and st.pcg_pipelined == 1
+    assert st.pcg_coarse_dim == 7 * (n_cam // 48)
+    assert st.pcg_iterations < 0.7 * plain.pcg_iterations
+    # the same minimum (a preconditioner changes the path of the inexact steps, not where they end)
+    assert st.status > 0 and abs(st.final_cost - plain.final_cost) <= 1e-6 * plain.final_cost
+    assert np.abs(pts1 - pts0).max() <= 1e-3
+    # every sum inside the kernel runs in a fixed order and the operator belongs to one iterate
+    assert again.final_cost == st.final_cost and again.pcg_iterations == st.pcg_iterations and again.iterations == st.iterations
+
+
+def test_single_launch_coarse_correction_is_skipped_where_its_limits_do_not_hold(monkeypatch):
+    # fewer than 256 cameras: no coarse space at all; the 9-number camera: the kernel is written for 6 x 6 blocks
+    small = syn.make_problem(60, 1500, 8000, seed=22)
+    st, _, _ = _solve_single_launch(small, monkeypatch, True, ftol=1e-10)
+    assert st.pcg_coarse_solves == 0 and st.pcg_coarse_dim == 0 and st.pcg_single_launch == st.iterations
+    b = _problem("bal", 300, 7500, 39000, seed=23)
+    with _engine(b, "bal", pcg_mode=2, ftol=1e-10) as eng:
+        stb = eng.solve()
+    assert stb.pcg_coarse_solves == 0 and stb.pcg_single_launch == stb.iterations and stb.status > 0

@@ -113,7 +113,7 @@ def test_bal_residuals_at_truth_are_the_observation_noise(venice_bal):
 def test_bal_full_solve_converges_to_the_noise_floor_on_both_schur_paths(venice_bal):
     costs = []
     for mode in (2, 1):                                   # explicit 9x9 blocks, matrix-free
-        with _bal_engine(venice_bal, schur_mode=mode) as eng:
+        with _bal_engine(venice_bal, schur_mode=mode, pcg_rtol=0.1) as eng:     # (same forcing term on both paths)
             st = eng.solve()
             cams, pts = eng.get_params()
         assert st.status in (1, 2, 3, 4) and st.schur_mode == mode

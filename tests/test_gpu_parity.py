@@ -244,7 +244,7 @@ def test_rejected_steps_raise_the_damping_and_recover(solver):
     # a start far from the optimum with almost no damping: several steps are rejected, the damping
     # grows without a new linearisation, and every PCG path ends at the same minimum
     p = syn.make_problem(12, 300, 1500, seed=4, window=8, point_sigma=0.8, rot_sigma=0.3, trans_sigma=0.5)
-    with make_engine(p, initial_lambda=1e-12, ftol=1e-10, **SOLVERS[solver]) as eng:
+    with make_engine(p, initial_lambda=1e-12, pcg_rtol=0.1, ftol=1e-10, **SOLVERS[solver]) as eng:
         st = eng.solve()
     assert st.status in (1, 2, 3, 4)
     assert st.iterations > st.accepted >= 5            # rejections happened
