@@ -88,13 +88,17 @@ typedef struct sfmba_options {
     int32_t pcg_mode;
     int32_t pcg_blocks;       /* workgroups of the single-launch solver; 0 = one per compute unit */
     int32_t camera_model;     /* enum sfmba_camera_model; default SFMBA_CAMERA_PINHOLE */
-    /* Two-level preconditioner of the launch-per-iteration PCG on the explicit matrix (pcg_mode 1,
-     * and whatever pcg_mode 0 resolves to when the single-launch solver does not apply): next to
-     * the block-Jacobi blocks, a coarse space of seven vectors (translation, rotation, scale of
-     * the world) per cluster of consecutive cameras, M^-1 = M_J^-1 + Z (Z'SZ)^-1 Z'.
+    /* Two-level preconditioner of PCG on the explicit matrix: next to the block-Jacobi blocks, a
+     * coarse space of seven vectors (translation, rotation, scale of the world) per cluster of
+     * consecutive cameras, M^-1 = M_J^-1 + Z (Z'SZ)^-1 Z'.
      *   0 = choose: built for 256 cameras and more, clusters of k = n_cameras / 100 cameras kept
-     *       within 48..128; a solve uses it once an earlier solve of the same sfmba_solve took
-     *       24 iterations or more;
+     *       within 48..128.  Launch-per-iteration solver: a solve uses it once an earlier solve of
+     *       the same sfmba_solve took 24 iterations or more.  Single-launch solver (pinhole
+     *       camera, pipelined form, at most 288 coarse unknowns, rows that reach at most four
+     *       clusters): after the first solve of 12 iterations or more the operator is set up from
+     *       that solve's matrix on a second stream while the next linearisation runs, and the
+     *       solves after it apply it inside the launch; it is renewed when a solve with it takes
+     *       48 iterations or more;
      *  -1 = never;
      *   k > 0 = clusters of k cameras (at least 48; raised where 7 n_cameras / k would exceed 4096),
      *       used from the first solve on; selects pcg_mode 1.

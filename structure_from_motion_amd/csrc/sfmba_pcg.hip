@@ -1294,15 +1294,44 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
             crows[c_rho][col] = col < a.c_npad ? e[col] * a.c_scale[col] : 0.0;
         }
     }
-    // G_r: per cluster slot of the row the sum over its lanes of Shat_rc Zhat_c, one coarse vector at a time
+    // G_r: per cluster slot of the row the sum over its lanes of Shat_rc Zhat_c, one coarse vector at a
+    // time (the column's factor is read once; the back substitution multiplies by the reciprocals
+    // of its diagonal)
     if (!flag && mine) {
         const bool act = lane < nb;
-        const double* __restrict__ Fc = a.F + 36 * (size_t)(act ? a.bsr_col[b0 + lane] : row);
-        const double* __restrict__ Zc = a.c_z + NV * ND * (size_t)(act ? a.bsr_col[b0 + lane] : row);
+        const int cc = act ? a.bsr_col[b0 + lane] : row;
+        const double* __restrict__ Fp = a.F + 36 * (size_t)cc;
+        const double* __restrict__ Zc = a.c_z + NV * ND * (size_t)cc;
+        double Fc[15], Fd[ND];          // strict lower triangle (row-major), reciprocal diagonal
+        {
+            int e = 0;
+#pragma unroll
+            for (int l = 1; l < ND; ++l)
+#pragma unroll
+                for (int k = 0; k < l; ++k) Fc[e++] = Fp[ND * l + k];
+#pragma unroll
+            for (int k = 0; k < ND; ++k) Fd[k] = 1.0 / Fp[ND * k + k];
+        }
+        double zn[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) zn[k] = Zc[k];
 #pragma unroll 1
         for (int j = 0; j < NV; ++j) {
-            double x[ND], P[ND];
-            back_subst(Fc, Zc + ND * j, x);
+            double z[ND], x[ND], P[ND];
+#pragma unroll
+            for (int k = 0; k < ND; ++k) z[k] = zn[k];
+            if (j + 1 < NV) {
+#pragma unroll
+                for (int k = 0; k < ND; ++k) zn[k] = Zc[ND * (j + 1) + k];       // the next vector is on its way
+            }
+            // F' x = z: x[k] = (z[k] - sum_{l > k} F[l][k] x[l]) / F[k][k]
+#pragma unroll
+            for (int k = ND - 1; k >= 0; --k) {
+                double v = z[k];
+#pragma unroll
+                for (int l = k + 1; l < ND; ++l) v -= Fc[l * (l - 1) / 2 + k] * x[l];
+                x[k] = v * Fd[k];
+            }
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
                 double t = S[ND * i] * x[0];
