@@ -844,6 +844,9 @@ void do_solve(H* h, sfmba_stats* out) {
         if (status == SFMBA_STATUS_MAX_NFEV && g_norm < gtol) status = SFMBA_STATUS_GTOL;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // (a coarse set-up started beside the last linearisation of a run that then ran out of
+    // iterations may still be at work on buffers the next call reuses)
+    if (h->fused_coarse_ready) HIP_TRY(hipStreamSynchronize(h->copy_stream));
     auto t1 = std::chrono::steady_clock::now();
     if (h->profile) collect_spans(h);
     st.status = status;

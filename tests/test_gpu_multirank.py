@@ -185,3 +185,24 @@ def test_sharded_solve_irregular_structure(solver):
         assert st["iterations"] == ref.iterations
         assert abs(st["final_cost"] - ref.final_cost) <= 1e-8 * ref.final_cost
         assert abs(o.cost(p, poses, pts) - st["final_cost"]) <= 1e-9 * st["final_cost"]
+
+
+def test_sharded_solve_with_the_coarse_correction_inside_the_single_launch():
+    # 300 cameras: the coarse space exists; every rank sets the operator up from the same all-reduced
+    # matrix on its own second stream and applies it inside its own (replicated) single-launch solve
+    p = syn.make_problem(300, 7500, 39000, seed=21)
+    opts = dict(linear_solver=1, schur_mode=2, pcg_mode=2, ftol=1e-10)
+    with E.Engine(**opts) as eng:
+        eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
+        ref = eng.solve()
+        ref_poses, ref_pts = eng.get_params()
+    assert ref.pcg_coarse_solves > 0 and ref.pcg_single_fallbacks == 0
+    out = solve_sharded(p, 2, **opts)
+    for st, poses, pts in out:
+        assert st["status"] == ref.status and st["iterations"] == ref.iterations
+        assert st["pcg_coarse_solves"] == ref.pcg_coarse_solves
+        # (two single-launch grids on one GPU may keep each other from becoming resident: a solve that
+        # falls back is redone launch by launch, with the same result up to rounding)
+        assert abs(st["final_cost"] - ref.final_cost) <= 1e-9 * ref.final_cost
+        assert np.abs(pts - ref_pts).max() <= 1e-6
+    assert np.array_equal(out[0][1], out[1][1])
