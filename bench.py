@@ -252,7 +252,8 @@ def main():
         return ab[f] / avg_s / 1e9 if avg_s > 0 else 0.0
 
     kernel_name = {"pairs": "k_schur_pairs", "spmv_pm": "k_spmv_pm", "spmv_cm": "k_spmv_cm",
-                   "bsr": ("k_pcg_pipe (per PCG iteration)" if ps.pcg_pipelined else "k_pcg_fused (per PCG iteration)")
+                   "bsr": (("k_pcg_pipe / k_pcg_pipe2 (per PCG iteration)" if ps.pcg_coarse_solves else "k_pcg_pipe (per PCG iteration)")
+                           if ps.pcg_pipelined else "k_pcg_fused (per PCG iteration)")
                    if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs

@@ -24,7 +24,7 @@ for setting in ("0", "1"):
     r = subprocess.run([sys.executable, "-c", CHILD, shape, scale], env=env, capture_output=True, text=True, timeout=300)
     lines = [l for l in r.stderr.splitlines() if "pcg single launch" in l]
     print("SFMBA_PCG_FUSED_COARSE=" + setting, "rc", r.returncode)
-    for l in [x for x in r.stderr.splitlines() if "pcg single launch" in x or "phases" in x][-9:]:
+    for l in [x for x in r.stderr.splitlines() if "pcg single launch" in x or "phases" in x or "us/iter" in x][-9:]:
         print("   ", l)
     print("   ", r.stdout.strip()[-400:])
     if r.returncode:

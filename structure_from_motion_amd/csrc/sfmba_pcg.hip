@@ -1097,7 +1097,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     }
     block_barrier();
     int flag = fail_lds ? 2 : 0;
-
     // the rows of C = D Einv D this workgroup needs: thread = (row of the list, column mod 16)
     const int c_rho = tid >> 4, c_part = tid & 15;
     const bool c_act = !flag && c_rho < NV * wgcl_n;
@@ -1177,12 +1176,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         if (lane < NV) red[w][2 + lane] = tau;
         block_barrier();
         if (tid < kC2Rec) {
+            // (all eight terms requested before the first is added: a loop with a branch per term
+            // pays the LDS latency eight times over)
+            const int sl = tid < 2 ? -2 : (tid - 2) / NV, col = tid < 2 ? tid : 2 + (tid - 2) - NV * sl;
             double sum = 0.0;
-            if (tid < 2) {
-                for (int v = 0; v < kFusedWaves; ++v) sum += red[v][tid];
-            } else {
-                const int sl = (tid - 2) / NV, j = (tid - 2) - NV * sl;
-                for (int v = 0; v < kFusedWaves; ++v) if (wslot[v] == sl) sum += red[v][2 + j];
+#pragma unroll
+            for (int h = 0; h < kFusedWaves; h += 4) {
+                double term[4];
+                int ws[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { term[v] = red[h + v][col]; ws[v] = wslot[h + v]; }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sum += (sl < 0 || ws[v] == sl) ? term[v] : 0.0;
             }
             st_word(drec + kC2Rec * ((size_t)(gen % kSlots) * G + blockIdx.x) + tid, (unsigned long long)__double_as_longlong(sum));
         }
