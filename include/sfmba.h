@@ -92,16 +92,17 @@ typedef struct sfmba_options {
      * coarse space of seven vectors (translation, rotation, scale of the world) per cluster of
      * consecutive cameras, M^-1 = M_J^-1 + Z (Z'SZ)^-1 Z'.
      *   0 = choose: built for 256 cameras and more, clusters of k = n_cameras / 100 cameras kept
-     *       within 48..128.  Launch-per-iteration solver: a solve uses it once an earlier solve of
-     *       the same sfmba_solve took 24 iterations or more.  Single-launch solver (pinhole
+     *       within 48..128.  After the first solve of an sfmba_solve that takes 12 iterations or
+     *       more the operator is set up from that solve's matrix on a second stream while the next
+     *       linearisation runs; the solves after it use it, and it is renewed when one of them
+     *       takes 48 iterations or more.  Launch-per-iteration solver: two more launches per
+     *       iteration apply it.  Single-launch solver (pinhole
      *       camera, pipelined form, at most 288 coarse unknowns, rows that reach at most four
-     *       clusters): after the first solve of 12 iterations or more the operator is set up from
-     *       that solve's matrix on a second stream while the next linearisation runs, and the
-     *       solves after it apply it inside the launch; it is renewed when a solve with it takes
-     *       48 iterations or more;
+     *       clusters): applied inside the launch;
      *  -1 = never;
      *   k > 0 = clusters of k cameras (at least 48; raised where 7 n_cameras / k would exceed 4096),
-     *       used from the first solve on; selects pcg_mode 1.
+     *       used from the first solve on, the operator set up from the matrix of every solve in
+     *       front of it; selects pcg_mode 1.
      * n_cl = n_cameras / k clusters, cluster i = cameras [i n_cameras / n_cl, (i+1) n_cameras / n_cl);
      * with fewer than two clusters no coarse space is built (one cluster would hold the gauge
      * directions of the whole problem, on which S vanishes up to the damping).  Cameras without

@@ -183,6 +183,7 @@ struct HandleData {
     // the same coarse space inside the single-launch PCG (k_pcg_pipe2): the operator is set up on
     // copy_stream after a solve that took fused_coarse_from iterations or more and used by the
     // solves after it
+    bool coarse_async = false;        // launch-per-iteration solver: operator from an earlier solve, set up on copy_stream
     bool fused_coarse_ok = false;     // structure and sizes admit it
     bool fused_coarse_ready = false;  // an operator has been set up (or is being set up) in this sfmba_solve
     int fused_coarse_from = 12;

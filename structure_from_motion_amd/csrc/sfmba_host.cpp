@@ -514,8 +514,15 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         h->fused_fallbacks++;
     }
     // two-level preconditioner: the coarse matrix belongs to one damping of one linearisation
-    const bool two_level = h->explicit_schur && h->coarse_built && h->coarse_on;
-    if (two_level && !h->coarse_valid) {
+    // two-level preconditioner: either the operator of this very matrix, set up here (asked for
+    // with pcg_coarse > 0, and the old policy), or the one set up on the second stream from the
+    // matrix of an earlier solve of the run (the default: see start_fused_coarse)
+    const bool async_op = h->coarse_async && h->fused_coarse_ready && !h->coarse_failed && !h->fused_pcg;
+    const bool two_level = h->explicit_schur && h->coarse_built && (h->coarse_on || async_op);
+    if (two_level && async_op && !h->coarse_on) {
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_done, 0));
+        h->coarse.Einv = h->fused_einv;
+    } else if (two_level && !h->coarse_valid) {
         Scope t(h, F_SCHUR);
         h->coarse.Einv = launch_coarse_setup(h->dev, h->coarse, h->stream);
         h->coarse_valid = true;
@@ -578,9 +585,14 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
             h->coarse_failed = true;
             return phase_pcg(h, lambda, allow_fused);
         }
-    } else if (h->explicit_schur && h->coarse_built && !h->coarse_failed && st.iter >= h->coarse_from) {
+    } else if (h->explicit_schur && h->coarse_built && !h->coarse_failed && !h->coarse_async && st.iter >= h->coarse_from) {
         h->coarse_on = true;        // solves only get longer as the damping falls
     }
+    // (with the operator set up on the second stream the switch-on rule sits in do_solve, which
+    // knows when the next linearisation starts)
+    if (h->explicit_schur && h->coarse_built && h->coarse_async && !h->coarse_failed && !h->coarse_on && !h->fused_pcg &&
+        h->solve_rtol > 0 && st.iter >= (two_level ? 4 * h->coarse_from : h->coarse_from))
+        h->fused_coarse_wanted = true;
     return st;
 }
 
@@ -1304,7 +1316,7 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     // Coarse space of the two-level preconditioner: clusters of consecutive cameras, never smaller
     // than the cameras one workgroup of the vector kernels handles (k_coarse_prolong relies on it)
     // and large enough that the dense coarse matrix stays below 4096 x 4096.
-    h->coarse_built = false; h->coarse_forced = false; h->coarse_on = false; h->coarse_valid = false;
+    h->coarse_built = false; h->coarse_forced = false; h->coarse_on = false; h->coarse_valid = false; h->coarse_async = false;
     // (left to choose: about a hundred clusters, of 48 to 128 cameras: the set-up grows with the
     // cube of their number, the iteration count with their size; measured best at the Venice shape
     // with 48 and at the Final shape with 128)
@@ -1375,6 +1387,13 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         h->coarse_built = true;
         h->coarse_from = kCoarseFromIterations;
         h->coarse_forced = coarse > 0;
+        // left to choose, the operator comes from an earlier solve's matrix and is set up beside the
+        // next linearisation instead of in front of the solve that uses it
+        h->coarse_async = coarse == 0;
+        if (const char* e = getenv("SFMBA_COARSE_ASYNC")) h->coarse_async = h->coarse_async && atoi(e) != 0;
+        // (its set-up costs the solves nothing, so it is switched on earlier than one set up in
+        // front of every solve: measured at 0.2, 0.5 and 1 x the Final shape)
+        if (h->coarse_async) h->coarse_from = 12;
         if (h->fused_pcg) {
             // the same space inside the single launch (k_pcg_pipe2), where its limits hold:
             // 6 x 6 blocks, the pipelined form, at most 256 workgroups of 8 rows, clusters of at
