@@ -996,7 +996,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
 // Block-Jacobi leaves the modes that move whole groups of cameras together (sfmba_coarse.hip);
 // the last linear solves of a run spend nine tenths of their iterations on them.  Here the
 // additive coarse correction M^-1 = M_J^-1 + Z C Z' (C = D Einv D of a coarse operator the host
-// hands over: the one of the LM iteration before, set up beside the other kernels) runs inside the
+// hands over: the one of an earlier LM iteration, set up beside the other kernels) runs inside the
 // single launch.  In the scaled variables the block-Jacobi part is the identity and
 // Mhat^-1 = I + Zhat C Zhat' with Zhat_c = F_c^-T Z_c.  Preconditioned pipelined CG:
 //     gamma = r'u, delta = w'u                         (published, summed by everybody later)
@@ -1007,14 +1007,15 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
 //     x += alpha p; r -= alpha s; u -= alpha q; w -= alpha z
 // The 7 coarse sums of a cluster are global sums like gamma and delta and travel with them: a
 // workgroup's record has 16 words (gamma, delta, the partial sums Zhat' w of the at most two
-// clusters its eight rows lie in), published before the product; every workgroup reads all
-// records, adds them in a fixed order and multiplies the rows of C it needs (the clusters of the
-// columns of its rows, at most kC2WgCl; 18 columns of 28 rows per thread, in registers) - so the
-// coarse correction costs no further trip across the dies, only three more workgroup barriers.
+// clusters its eight rows lie in), published before the product; thread (cluster, vector) of every
+// workgroup reads that sum's terms from the records of the workgroups with rows in the cluster and
+// adds them in a fixed order, then the workgroup multiplies the rows of C it needs (the clusters of
+// the columns of its rows, at most kC2WgCl x 7 rows, kept in LDS; thread = (row, column mod 16)) -
+// so the coarse correction costs no further trip across the dies, only two more workgroup barriers.
 // Restrictions, checked by the host: those of k_pcg_pipe, 6 x 6 blocks, at most 256 workgroups,
 // clusters of at least 8 cameras whose rows lie in at most kC2Span workgroups, a coarse dimension of
-// at most 288 after padding, at most
-// kC2RowCl clusters among the columns of a row and kC2WgCl among those of a workgroup's rows.
+// at most 288 after padding, at most kC2WgCl clusters among the columns of a workgroup's rows
+// (and so at most kC2RowCl = kC2WgCl among those of one row).
 constexpr int kC2Rec = kPcgRecWords;    // words of a workgroup's record
 constexpr int kC2RowCl = 4;
 constexpr int kC2WgCl = 4;
