@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
 // workgroup reads that sum's terms from the records of the workgroups with rows in the cluster and
 // adds them in a fixed order, then the workgroup multiplies the rows of C it needs (the clusters of
 // the columns of its rows, at most kC2WgCl x 7 rows, kept in LDS; thread = (row, column mod 16)) -
-// so the coarse correction costs no further trip across the dies, only two more workgroup barriers.
+// so the coarse correction costs no further trip across the dies, only one more workgroup barrier.
 // Restrictions, checked by the host: those of k_pcg_pipe, 6 x 6 blocks, at most 256 workgroups,
 // clusters of at least 8 cameras whose rows lie in at most kC2Span workgroups, a coarse dimension of
 // at most 288 after padding, at most kC2WgCl clusters among the columns of a workgroup's rows
