@@ -31,9 +31,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, GB/s
 def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks, cam_dim=6):
     """Compulsory HBM bytes per launch of the per-launch kernels (int32 indices, f64 data).
 
-    pairs    explicit Schur assembly k_schur_pairs: three indices per pair (12), every
-             observation's three seed words once (24), every point's inverse block once (48), one
-             36-double partial row per chunk (288; 81 doubles for the 9-number camera)
+    pairs    explicit Schur assembly k_schur_pairs: the point index of every pair (4), every point
+             (32) and its inverse block (48) once, per chunk its record (16) and one 36-double
+             partial row (288; 81 doubles for the 9-number camera)
     bsr      k_pcg_spmv_bsr: the block-CSR matrix once (288 + 4 per block, n_pairs here = blocks),
              three vectors read and two written per camera (240); k_pcg_fused: see main()
     spmv_pm  implicit matvec, point-major half: camera index + seed record per observation (36),
@@ -42,7 +42,7 @@ def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks, cam
     spmv_cm  implicit matvec, camera-major half: point index + seeds per observation (28),
              product gathered once per point (32), camera (96), 48 + 12 per chunk"""
     return {
-        "pairs": 12 * n_pairs + 24 * n_obs + 48 * n_pts + 8 * cam_dim * cam_dim * n_pair_chunks,
+        "pairs": 4 * n_pairs + 80 * n_pts + (16 + 8 * cam_dim * cam_dim) * n_pair_chunks,
         "spmv_pm": 40 * n_obs + 80 * n_pts + 120 * n_cam,
         "spmv_cm": 28 * n_obs + 32 * n_pts + 96 * n_cam + 60 * n_chunks,
     }

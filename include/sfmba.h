@@ -303,8 +303,8 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
 /* One of the integer arrays sfmba_set_problem derived from the index arrays, by name: the
  * point-major order (pt_ptr, pm_cam, pm_pt, pm_orig, new2old), the camera-major order (cm_pt,
  * chunk_cam, chunk_beg, cam_chunk_ptr), wtile_beg, and for the explicit reduced matrix ublk_r,
- * ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg, pair_a, pair_b,
- * pair_p, bsr_ptr, bsr_col, bsr_diag.  *count receives the length; out may be NULL to ask for it.
+ * ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg, pair_p,
+ * bsr_ptr, bsr_col, bsr_diag.  *count receives the length; out may be NULL to ask for it.
  * Lets the tests compare the two set-up paths (options.setup_mode) array by array. */
 int sfmba_get_structure(sfmba_handle* h, const char* name, int32_t* out, int64_t capacity, int64_t* count);
 

@@ -48,6 +48,28 @@ __device__ __forceinline__ Seed project_seed(const Cam& k, double X0, double X1,
     return s;
 }
 
+// 1 / y by the hardware estimate and two Newton steps (five instructions against the fourteen of
+// an IEEE division; last-bit accuracy, no scaling: |y| must lie well inside the normal range).  For
+// derivative blocks only - residuals and costs use the division.
+__device__ __forceinline__ double newton_rcp(double y) {
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(r, fma(-y, r, 1.0), r);
+    r = fma(r, fma(-y, r, 1.0), r);
+    return r;
+}
+
+// project_seed with newton_rcp (same guard).
+__device__ __forceinline__ Seed project_seed_jac(const Cam& k, double X0, double X1, double X2) {
+    double Y0 = k.q[0] * X0 + k.q[1] * X1 + k.q[2] * X2 + k.t[0];
+    double Y1 = k.q[3] * X0 + k.q[4] * X1 + k.q[5] * X2 + k.t[1];
+    double Y2 = k.q[6] * X0 + k.q[7] * X1 + k.q[8] * X2 + k.t[2];
+    Seed s;
+    s.iz = (Y2 != 0.0) ? newton_rcp(Y2) : 1.0;
+    s.x = Y0 * s.iz;
+    s.y = Y1 * s.iz;
+    return s;
+}
+
 // Residual (reprojection minus observation), bundle_adjustment.py:50.
 __device__ __forceinline__ void residual(const Seed& s, const Intr& K, double u, double v,
                                          double& ru, double& rv) {
@@ -278,7 +300,15 @@ struct Pinhole {
         u.t[0] = u.t[1] = u.t[2] = 0.0;
         return u;
     }
+    // the whole camera in scalar registers
+    static __device__ __forceinline__ Cam uniform(const Cam& k) {
+        Cam u = uniform_rot(k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u.t[i] = wave_uniform(k.t[i]);
+        return u;
+    }
     static __device__ __forceinline__ Seed seed(const Cam& k, double X0, double X1, double X2) { return project_seed(k, X0, X1, X2); }
+    static __device__ __forceinline__ Seed seed_jac(const Cam& k, double X0, double X1, double X2) { return project_seed_jac(k, X0, X1, X2); }
     static __device__ __forceinline__ Obs obs(const Seed& s, const Cam&, const Intr& K) { return Obs{s, K}; }
     static __device__ __forceinline__ void residual(const Obs& o, double u, double v, double& ru, double& rv) { sfmba::residual(o.s, o.K, u, v, ru, rv); }
     static __device__ __forceinline__ void jac_cam(const Obs& o, double* jc) { sfmba::jac_cam(o.s, o.K, jc); }
@@ -350,6 +380,12 @@ struct Bal {
         u.f = wave_uniform(k.f); u.k1 = wave_uniform(k.k1); u.k2 = wave_uniform(k.k2);
         return u;
     }
+    static __device__ __forceinline__ Cam uniform(const Cam& k) {
+        Cam u = uniform_rot(k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u.t[i] = wave_uniform(k.t[i]);
+        return u;
+    }
     // no guard against Z == 0: the reference divides (ba_test.py:82) and SciPy then refuses the
     // non-finite residual
     static __device__ __forceinline__ Seed seed(const Cam& k, double X0, double X1, double X2) {
@@ -358,6 +394,16 @@ struct Bal {
         const double Y2 = k.q[6] * X0 + k.q[7] * X1 + k.q[8] * X2 + k.t[2];
         Seed s;
         s.iz = 1.0 / Y2;
+        s.x = Y0 * s.iz;
+        s.y = Y1 * s.iz;
+        return s;
+    }
+    static __device__ __forceinline__ Seed seed_jac(const Cam& k, double X0, double X1, double X2) {
+        const double Y0 = k.q[0] * X0 + k.q[1] * X1 + k.q[2] * X2 + k.t[0];
+        const double Y1 = k.q[3] * X0 + k.q[4] * X1 + k.q[5] * X2 + k.t[1];
+        const double Y2 = k.q[6] * X0 + k.q[7] * X1 + k.q[8] * X2 + k.t[2];
+        Seed s;
+        s.iz = newton_rcp(Y2);
         s.x = Y0 * s.iz;
         s.y = Y1 * s.iz;
         return s;

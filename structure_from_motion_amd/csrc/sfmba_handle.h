@@ -158,8 +158,8 @@ struct HandleData {
     bool explicit_schur = false;
     int n_ublk = 0, n_pchunks = 0, nnzb = 0, nb_bsr = 0, dot_off = 0;
     int64_t n_pairs = 0;
-    DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg;
-    DBuf<int> pair_a, pair_b, pair_p, bsr_ptr, bsr_col, bsr_diag;
+    DBuf<int> ublk_r, ublk_c, ublk_chunk_ptr, ublk_pos, ublk_pos_t, ublk_diag, pchunk_blk, pchunk_beg, pchunk_rec;
+    DBuf<int> pair_p, bsr_ptr, bsr_col, bsr_diag;
     DBuf<double> pair_part, Bsum, Sfull;
     // single-launch PCG on the scaled system
     bool fused_pcg = false, fused_armed = false, fused_refused = false;

@@ -206,7 +206,8 @@ void refresh_dev(H* h) {
     d.ublk_r = h->ublk_r.p; d.ublk_c = h->ublk_c.p; d.ublk_chunk_ptr = h->ublk_chunk_ptr.p;
     d.ublk_pos = h->ublk_pos.p; d.ublk_pos_t = h->ublk_pos_t.p; d.ublk_diag = h->ublk_diag.p;
     d.pchunk_blk = h->pchunk_blk.p; d.pchunk_beg = h->pchunk_beg.p;
-    d.pair_a = h->pair_a.p; d.pair_b = h->pair_b.p; d.pair_p = h->pair_p.p;
+    d.pchunk_rec = reinterpret_cast<const int4*>(h->pchunk_rec.p);
+    d.pair_p = h->pair_p.p;
     d.pair_part = h->pair_part.p; d.Bsum = h->Bsum.p;
     d.bsr_ptr = h->bsr_ptr.p; d.bsr_col = h->bsr_col.p; d.bsr_diag = h->bsr_diag.p; d.Sfull = h->Sfull.p;
 }
@@ -1049,7 +1050,7 @@ namespace {
 
 void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, const int64_t* pt_idx,
                            const std::vector<int64_t>& pre, const std::vector<int>& pt_ptr,
-                           const std::vector<int>& pm_cam, const std::vector<int>& pm2cm) {
+                           const std::vector<int>& pm_cam) {
     const int n_cam = (int)h->n_cam, np = h->n_pts, no = h->n_obs;
     SetupTrace tr;
     const SchurPlan plan = plan_schur(h);
@@ -1183,16 +1184,13 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         for (int t = 0; t < nt; ++t) { const int c = tcount[t][u]; tcount[t][u] = tot; tot += c; }   // offset inside the block
         bcount[u + 1] = bcount[u] + tot;
     }
-    std::vector<int> pa((size_t)n_pairs), pb((size_t)n_pairs), pp((size_t)n_pairs);
+    std::vector<int> pp((size_t)n_pairs);
     run_threads([&](int t) {
         BlkCache bc;
         std::vector<int>& off = tcount[t];
-        for_each_pair(pbeg[t], pbeg[t + 1], bc, [&](int u, int a, int b, int p) {
-            const int k = bcount[u] + off[u]++;
-            pa[k] = pm2cm[a]; pb[k] = pm2cm[b]; pp[k] = p;
-        });
+        for_each_pair(pbeg[t], pbeg[t + 1], bc, [&](int u, int, int, int p) { pp[bcount[u] + off[u]++] = p; });
     });
-    // (pa / pb are positions in the camera-major order: the pair kernel reads those seed arrays)
+    // (a pair is listed by its point alone: the pair kernel rebuilds both observations from it)
     tr.lap("schur: pair lists");
     // pair chunks
     int pchunk = 512;
@@ -1229,7 +1227,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
         h->ublk_diag.upload(udiag, st);
     }
     h->pchunk_blk.upload(pchunk_blk, st); h->pchunk_beg.upload(pchunk_beg, st);
-    h->pair_a.upload(pa, st); h->pair_b.upload(pb, st); h->pair_p.upload(pp, st);
+    h->pair_p.upload(pp, st);
     h->bsr_ptr.upload(bsr_ptr, st); h->bsr_col.upload(bsr_col, st); h->bsr_diag.upload(bsr_diag, st);
     h->n_ublk = n_ublk; h->n_pchunks = (int)pchunk_blk.size(); h->nnzb = nnzb; h->n_pairs = n_pairs;
     h->bsr_ptr_host = bsr_ptr; h->bsr_col_host = bsr_col;
@@ -1255,6 +1253,13 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     h->Bsum.alloc((size_t)n_ublk * nn + (size_t)n_cam * h->cv);     // + the per-camera sums T_c, one collective
     h->Sfull.alloc((size_t)nnzb * nn);
     h->Bsum.zero(st); h->Sfull.zero(st);
+    h->pchunk_rec.alloc(4 * (size_t)std::max(h->n_pchunks, 1));
+    if (h->n_pchunks > 0) {
+        Dev d{};
+        d.n_pchunks = h->n_pchunks; d.pchunk_blk = h->pchunk_blk.p; d.pchunk_beg = h->pchunk_beg.p;
+        d.ublk_r = h->ublk_r.p; d.ublk_c = h->ublk_c.p;
+        launch_pchunk_records(d, reinterpret_cast<int4*>(h->pchunk_rec.p), st);
+    }
     HIP_TRY(hipStreamSynchronize(st));
     h->explicit_schur = true;
     // one camera-major pass per linearisation instead of two (k_lin_sdiag_cm): measured for the
@@ -1620,7 +1625,7 @@ void host_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx, const doubl
     h->new2old_dev.upload(h->new2old, st);
     h->device_built = false;
     tr.lap("uploads");
-    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam, pm2cm);
+    build_schur_structure(h, n_obs, cam_idx, pt_idx, pre, pt_ptr, pm_cam);
     HIP_TRY(hipStreamSynchronize(st));      // the uploads read host vectors that end here
     tr.lap("schur structure (total)");
 }
@@ -2195,7 +2200,7 @@ int sfmba_get_structure(sfmba_handle* h, const char* name, int32_t* out, int64_t
             {"wtile_beg", &h->wtile_beg}, {"new2old", &h->new2old_dev},
             {"ublk_r", &h->ublk_r}, {"ublk_c", &h->ublk_c}, {"ublk_chunk_ptr", &h->ublk_chunk_ptr}, {"ublk_pos", &h->ublk_pos},
             {"ublk_pos_t", &h->ublk_pos_t}, {"ublk_diag", &h->ublk_diag}, {"pchunk_blk", &h->pchunk_blk}, {"pchunk_beg", &h->pchunk_beg},
-            {"pair_a", &h->pair_a}, {"pair_b", &h->pair_b}, {"pair_p", &h->pair_p},
+            {"pair_p", &h->pair_p},
             {"bsr_ptr", &h->bsr_ptr}, {"bsr_col", &h->bsr_col}, {"bsr_diag", &h->bsr_diag}};
         const DBuf<int>* b = nullptr;
         for (const Entry& e : table) if (strcmp(e.name, name) == 0) b = e.buf;

@@ -8,7 +8,15 @@
 
 namespace sfmba {
 
-constexpr int kBlock = 256;        // threads per workgroup of every kernel (4 wavefronts)
+constexpr int kBlock = 256;        // threads per workgroup (4 wavefronts) unless a kernel says otherwise
+// Kernels in which every wavefront owns one camera chunk of up to 512 observations: the chunks
+// differ in length and a workgroup's registers and LDS return to the compute unit only when its
+// last wavefront has finished, so two wavefronts per workgroup keep more of them resident than
+// four (fused camera-major pass at the Venice shape: 138 -> 117 us per launch).
+#ifndef SFMBA_CM_BLOCK
+#define SFMBA_CM_BLOCK 128
+#endif
+constexpr int kCmBlock = SFMBA_CM_BLOCK;
 constexpr int kChunk = 512;        // observations per camera-major chunk (one wavefront each)
 constexpr int kMaxScalBlocks = 1 << 18;
 
@@ -139,7 +147,8 @@ struct Dev {
     const int* ublk_diag;                         // [n_cam] upper block (c, c) of every camera
     const int* ublk_pos; const int* ublk_pos_t;   // [n_ublk] slots of (r,c) and (c,r) in Sfull
     const int* pchunk_blk; const int* pchunk_beg; // [n_pchunks], [n_pchunks+1]
-    const int* pair_a; const int* pair_b; const int* pair_p;   // [n_pairs] camera-major indices of the two observations, point
+    const int4* pchunk_rec;   // [n_pchunks] (first pair, end, row camera, column camera): what a wavefront of the pair kernel needs, one load
+    const int* pair_p;        // [n_pairs] the point of every pair, by block and, inside a block, by point
     double* pair_part;        // [n_pchunks][ND * ND]
     double* Bsum;             // [n_ublk][ND * ND] sum W_a Vinv W_b' per upper block (all ranks' sum)
     const int* bsr_ptr; const int* bsr_col; const int* bsr_diag;   // [n_cam+1], [nnzb], [n_cam]
@@ -230,6 +239,7 @@ int blocks_cam(const Dev& d);
 // sfmba_schur.hip
 int bsr_blocks(const Dev& d);
 void launch_schur_pairs(const Dev& d, hipStream_t st);
+void launch_pchunk_records(const Dev& d, int4* rec, hipStream_t st);
 void launch_block_reduce(const Dev& d, hipStream_t st);
 // full matrix, preconditioner, right-hand side; with `scaled` also F, bhat, Shat of the single-launch PCG
 void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st);

@@ -20,7 +20,7 @@
 namespace sfmba {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kBlock / 64); }
+static int blocks_chunk(const Dev& d) { return cdiv(d.n_chunks, kCmBlock / 64); }
 
 // Store one block partial of a scalar slot.
 __device__ __forceinline__ void put_partial(const Dev& d, int slot, double v) {
@@ -258,11 +258,11 @@ __device__ __forceinline__ void chunk_store(const Dev& d, int q, const double (&
 // kGrad: only g_c is wanted (see k_lin_pm): the U part of the chunk row is written as zeros and the
 // camera-major seeds are left alone.
 template <class M, bool kGrad = false>
-__global__ __launch_bounds__(kBlock) void k_lin_cm(Dev d) {
+__global__ __launch_bounds__(kCmBlock) void k_lin_cm(Dev d) {
     constexpr int ND = M::ND, NU = M::NU, NV = M::NV;
-    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
+    __shared__ __attribute__((aligned(16))) double lds[(kCmBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kCmBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -342,11 +342,11 @@ __global__ __launch_bounds__(kBlock) void k_damp_pm(Dev d, double lambda) {
 // Camera-major: chunk partials of T_c = sum W Vinv W' (packed upper) and sum W s0,
 // W = Jc' Jp (ND x 3), formed as Jc' (Jp Vinv Jp') Jc without the ND x 3 intermediates.
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
+__global__ __launch_bounds__(kCmBlock) void k_sdiag_cm(Dev d) {
     constexpr int ND = M::ND, NU = M::NU, NV = M::NV;
-    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
+    __shared__ __attribute__((aligned(16))) double lds[(kCmBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kCmBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
         int p;
         if constexpr (kAhead) { p = pn; if (k + 64 < k1) pn = d.cm_pt[k + 64]; }
         else p = d.cm_pt[k];
-        Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];
+        Seed s; s.x = d.cm_sx[k]; s.y = d.cm_sy[k]; s.iz = d.cm_siz[k];      // (stored by k_lin_cm)
         const typename M::Obs ob = M::obs(s, cam, d.K);
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
         double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
@@ -414,11 +414,11 @@ __global__ __launch_bounds__(kBlock) void k_sdiag_cm(Dev d) {
 // separate passes (k_finish_diag: S_cc = U* - T - B) finds what it expects: UG = (upper, g_c) as
 // above, T = (T_ii on the diagonal, zero off it | sum W s0).
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_lin_sdiag_cm(Dev d) {
+__global__ __launch_bounds__(kCmBlock) void k_lin_sdiag_cm(Dev d) {
     constexpr int ND = M::ND, NU = M::NU, NF = NU + 3 * ND;
-    __shared__ __attribute__((aligned(16))) double lds[(kBlock / 64) * 64 * 16];
+    __shared__ __attribute__((aligned(16))) double lds[(kCmBlock / 64) * 64 * 16];
     const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kCmBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -458,7 +458,6 @@ __global__ __launch_bounds__(kBlock) void k_lin_sdiag_cm(Dev d) {
         const typename M::Obs ob = M::obs(s, cam, d.K);
         double ru, rv;
         M::residual(ob, uv.x, uv.y, ru, rv);
-        d.cm_sx[k] = s.x; d.cm_sy[k] = s.y; d.cm_siz[k] = s.iz;
         double jc[2 * ND], a[3], b[3];
         M::jac_cam(ob, jc);
         M::jac_pt(ob, cam.q, a, b);
@@ -614,11 +613,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pm(Dev d, const double* __restr
 
 // Schur matvec, camera-major half: chunk partials of sum_o Jc' (Jp s_p)  (ND values).
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_spmv_cm(Dev d, const double4* __restrict__ svec, const PcgState* __restrict__ state) {
+__global__ __launch_bounds__(kCmBlock) void k_spmv_cm(Dev d, const double4* __restrict__ svec, const PcgState* __restrict__ state) {
     constexpr int ND = M::ND;
     if (state && state->done) return;
     const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kCmBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -899,9 +898,9 @@ static void run_jobs(const Dev& d, const FinalizeJobs& j, hipStream_t st) {
 // camera-major: chunk partials (sum, count).  The per-view quantity the reference prints after
 // every bundle adjustment (/root/reference/view.py:103-119, utils.py:337-352).
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_reproj_cm(Dev d) {
+__global__ __launch_bounds__(kCmBlock) void k_reproj_cm(Dev d) {
     const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kCmBlock / 64) + (threadIdx.x >> 6);
     if (q >= d.n_chunks) return;
     const int c = __builtin_amdgcn_readfirstlane(d.chunk_cam[q]);
     const int k0 = __builtin_amdgcn_readfirstlane(d.chunk_beg[q]);
@@ -923,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void k_reproj_cm(Dev d) {
     }
 }
 void launch_reproj_cm(const Dev& d, double* out2, hipStream_t st) {
-    if (d.n_chunks > 0) SFMBA_LAUNCH(d, k_reproj_cm, dim3(blocks_chunk(d)), st, d);
+    if (d.n_chunks > 0) SFMBA_LAUNCH_T(d, k_reproj_cm, dim3(blocks_chunk(d)), dim3(kCmBlock), st, d);
     launch_chunk_reduce(d, 2, out2, st);
 }
 
@@ -1004,11 +1003,11 @@ void launch_lin_cm(const Dev& d, hipStream_t st, bool grad_only) {
     if (d.n_chunks == 0) return;
     const dim3 grid(blocks_chunk(d));
     if (grad_only) {
-        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_cm<Bal, true>), grid, dim3(kBlock), 0, st, d);
-        else hipLaunchKernelGGL((k_lin_cm<Pinhole, true>), grid, dim3(kBlock), 0, st, d);
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_cm<Bal, true>), grid, dim3(kCmBlock), 0, st, d);
+        else hipLaunchKernelGGL((k_lin_cm<Pinhole, true>), grid, dim3(kCmBlock), 0, st, d);
     } else {
-        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_cm<Bal, false>), grid, dim3(kBlock), 0, st, d);
-        else hipLaunchKernelGGL((k_lin_cm<Pinhole, false>), grid, dim3(kBlock), 0, st, d);
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_cm<Bal, false>), grid, dim3(kCmBlock), 0, st, d);
+        else hipLaunchKernelGGL((k_lin_cm<Pinhole, false>), grid, dim3(kCmBlock), 0, st, d);
     }
 }
 void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st) {
@@ -1016,7 +1015,7 @@ void launch_chunk_reduce(const Dev& d, int nvals, double* out, hipStream_t st) {
 }
 int lin_sdiag_values(int model) { return model == MODEL_BAL ? Bal::NU + 3 * Bal::ND : Pinhole::NU + 3 * Pinhole::ND; }
 void launch_lin_sdiag_cm(const Dev& d, double* tpart, hipStream_t st) {
-    if (d.n_chunks > 0) SFMBA_LAUNCH(d, k_lin_sdiag_cm, dim3(blocks_chunk(d)), st, d);
+    if (d.n_chunks > 0) SFMBA_LAUNCH_T(d, k_lin_sdiag_cm, dim3(blocks_chunk(d)), dim3(kCmBlock), st, d);
     SFMBA_LAUNCH(d, k_chunk_reduce_fused, dim3(cdiv(d.n_cam * 2 * cam_sums(d.model), kBlock)), st, d, tpart);
 }
 void launch_damp_pm(const Dev& d, double lambda, hipStream_t st) {
@@ -1025,7 +1024,7 @@ void launch_damp_pm(const Dev& d, double lambda, hipStream_t st) {
 }
 void launch_sdiag_cm(const Dev& d, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    SFMBA_LAUNCH(d, k_sdiag_cm, dim3(blocks_chunk(d)), st, d);
+    SFMBA_LAUNCH_T(d, k_sdiag_cm, dim3(blocks_chunk(d)), dim3(kCmBlock), st, d);
 }
 void launch_precond(const Dev& d, double lambda, hipStream_t st) {
     SFMBA_LAUNCH(d, k_precond, dim3(blocks_cam(d)), st, d, lambda);
@@ -1036,7 +1035,7 @@ void launch_spmv_pm(const Dev& d, const double* x, const PcgState* state, hipStr
 }
 void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hipStream_t st) {
     if (d.n_chunks == 0) return;
-    SFMBA_LAUNCH(d, k_spmv_cm, dim3(blocks_chunk(d)), st, d, svec, state);
+    SFMBA_LAUNCH_T(d, k_spmv_cm, dim3(blocks_chunk(d)), dim3(kCmBlock), st, d, svec, state);
 }
 void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y, hipStream_t st) {
     SFMBA_LAUNCH(d, k_schur_apply, dim3(blocks_cam(d)), st, d, x, lambda, y);

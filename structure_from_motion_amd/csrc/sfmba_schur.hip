@@ -2,12 +2,12 @@
 //
 // S = (U + lambda D_c) - sum_p W_p (V_p + lambda D_p)^-1 W_p' has an ND x ND block (ND = 6 or 9
 // tangent numbers per camera, by camera model) for every pair of
-// cameras that share a point.  The host lists, per upper block (r <= c), the pairs of distinct
+// cameras that share a point.  The set-up lists, per upper block (r <= c), the point of every pair of distinct
 // observations (a, b) of one point with camera(a) = r and camera(b) = c (an observation paired
 // with itself belongs to the diagonal block and is summed by the camera-major pass k_sdiag_cm), sorted by block and cut
 // into chunks; one wavefront owns one chunk, both cameras are wave-uniform, every lane forms
 //     Jc_a' (Jp_a Vinv_p Jp_b') Jc_b          (ND x 2 . 2x2 . 2 x ND)
-// for its pairs from the stored camera-major seeds, sums in registers, and the wavefront reduces the ND^2 sums
+// for its pairs from the point and the two cameras, sums in registers, and the wavefront reduces the ND^2 sums
 // through an LDS tile into one partial row per chunk.  A per-block pass adds the chunk rows
 // in fixed order (bitwise reproducible, no atomics), a finishing pass mirrors the upper blocks
 // into a full block-CSR matrix and adds the damped U blocks on the diagonal.  The reduced system
@@ -24,56 +24,39 @@ namespace sfmba {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// A load that writes LDS directly: lane l's kBytes land at dst + l * kBytes (dst the same in every lane).
 // Rows [I0, I1) of the block sums of pair chunk q.
+//
+// A pair's operands are its point and the point's damped inverse block; both observations'
+// seeds are rebuilt from the point and the two wave-uniform cameras (derivatives only: the
+// reciprocal of the depth by two Newton steps).  Reading the seeds the camera-major pass stored
+// instead (two more indices per pair, six 8-byte gathers) kept the vector caches busier than the
+// arithmetic this adds keeps the vector unit: 195 -> 155 us per launch at the Venice shape.
 template <class M, int I0, int I1>
 __device__ __forceinline__ void schur_pairs_rows(const Dev& d, int q, int lane, double* lds) {
     constexpr int ND = M::ND, NN = (I1 - I0) * ND;
-    const int blk = __builtin_amdgcn_readfirstlane(d.pchunk_blk[q]);
-    const int k0 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q]);
-    const int k1 = __builtin_amdgcn_readfirstlane(d.pchunk_beg[q + 1]);
-    const int r = __builtin_amdgcn_readfirstlane(d.ublk_r[blk]);
-    const int c = __builtin_amdgcn_readfirstlane(d.ublk_c[blk]);
-    // both cameras are the same for the whole wavefront: their rotations live in scalar registers
-    const typename M::Cam camr = M::uniform_rot(M::load_rot(d.cams, r));
-    const typename M::Cam camc = M::uniform_rot(M::load_rot(d.cams, c));
+    const int4 rec = d.pchunk_rec[q];
+    const int k0 = __builtin_amdgcn_readfirstlane(rec.x);
+    const int k1 = __builtin_amdgcn_readfirstlane(rec.y);
+    const int r = __builtin_amdgcn_readfirstlane(rec.z);
+    const int c = __builtin_amdgcn_readfirstlane(rec.w);
+    // both cameras are the same for the whole wavefront: they live in scalar registers
+    const typename M::Cam camr = M::uniform(M::load(d.cams, r));
+    const typename M::Cam camc = M::uniform(M::load(d.cams, c));
     double acc[NN];
 #pragma unroll
     for (int i = 0; i < NN; ++i) acc[i] = 0.0;
-    // 9 x 9 blocks: a software pipeline over the rounds, this round's arithmetic overlapping the
-    // next round's gathers (530 -> 440 us per launch at the Venice shape; with 6 x 6 blocks, where
-    // three wavefronts per SIMD already overlap the two rounds of latency, requesting the indices
-    // ahead alone costs 25 %)
-    constexpr bool kAhead = ND > 6;
-    struct Gathered { Seed sa, sb; double2 v01, v23, v45; };
-    auto gather = [&](int ja, int jb, int p) {
-        // seeds from the camera-major arrays: the observations of one camera are sorted by point
-        // there, so neighbouring pairs of a block read neighbouring words (several per cache line)
+    struct Gathered { double2 x01, x2, v01, v23, v45; };
+    auto gather = [&](int p) {
         Gathered g;
-        g.sa.x = d.cm_sx[ja]; g.sa.y = d.cm_sy[ja]; g.sa.iz = d.cm_siz[ja];
-        g.sb.x = d.cm_sx[jb]; g.sb.y = d.cm_sy[jb]; g.sb.iz = d.cm_siz[jb];
+        const double2* xp = reinterpret_cast<const double2*>(d.X + p);
         const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
+        g.x01 = xp[0]; g.x2 = xp[1];
         g.v01 = vi[0]; g.v23 = vi[1]; g.v45 = vi[2];
         return g;
     };
-    // kAhead: indices two rounds ahead, gathered values one round ahead
-    const int kf = k0 + lane;
-    int nja = 0, njb = 0, np_ = 0;
-    Gathered gn{};
-    if (kAhead) {
-        if (kf < k1) gn = gather(d.pair_a[kf], d.pair_b[kf], d.pair_p[kf]);
-        if (kf + 64 < k1) { nja = d.pair_a[kf + 64]; njb = d.pair_b[kf + 64]; np_ = d.pair_p[kf + 64]; }
-    }
-    for (int k = kf; k < k1; k += 64) {
-        Gathered g;
-        if constexpr (kAhead) {
-            g = gn;
-            const int ja = nja, jb = njb, p = np_;
-            if (k + 128 < k1) { nja = d.pair_a[k + 128]; njb = d.pair_b[k + 128]; np_ = d.pair_p[k + 128]; }
-            if (k + 64 < k1) gn = gather(ja, jb, p);
-        } else {
-            g = gather(d.pair_a[k], d.pair_b[k], d.pair_p[k]);
-        }
-        const Seed sa = g.sa, sb = g.sb;
+    auto accumulate = [&](const Gathered& g) {
+        const Seed sa = M::seed_jac(camr, g.x01.x, g.x01.y, g.x2.x), sb = M::seed_jac(camc, g.x01.x, g.x01.y, g.x2.x);
         const double2 v01 = g.v01, v23 = g.v23, v45 = g.v45;
         const typename M::Obs oa = M::obs(sa, camr, d.K), ob = M::obs(sb, camc, d.K);
         double aa[3], ab[3], ba[3], bb[3];
@@ -105,6 +88,32 @@ __device__ __forceinline__ void schur_pairs_rows(const Dev& d, int q, int lane, 
             for (int j = 0; j < ND; ++j)
                 acc[ND * (i - I0) + j] += kZ && j == 3 ? l0 * jcb[j] : kZ && j == 4 ? l1 * jcb[ND + j] : l0 * jcb[j] + l1 * jcb[ND + j];
         }
+    };
+    // The point index is requested a round ahead (6 x 6 blocks, three wavefronts per SIMD) or two
+    // rounds ahead with the operands one round ahead (9 x 9 blocks: this round's arithmetic
+    // overlaps the next round's gathers, 530 -> 440 us per launch at the Venice shape; with 6 x 6
+    // blocks the registers of that pipeline cost the third wavefront and 8 %).
+    constexpr bool kAhead = ND > 6;
+    const int kf = k0 + lane;
+    if constexpr (kAhead) {
+        int pn = 0;
+        Gathered gn{};
+        if (kf < k1) gn = gather(d.pair_p[kf]);
+        if (kf + 64 < k1) pn = d.pair_p[kf + 64];
+        for (int k = kf; k < k1; k += 64) {
+            const Gathered g = gn;
+            const int p = pn;
+            if (k + 128 < k1) pn = d.pair_p[k + 128];
+            if (k + 64 < k1) gn = gather(p);
+            accumulate(g);
+        }
+    } else {
+        int pn = kf < k1 ? d.pair_p[kf] : 0;
+        for (int k = kf; k < k1; k += 64) {
+            const int p = pn;
+            if (k + 64 < k1) pn = d.pair_p[k + 64];
+            accumulate(gather(p));
+        }
     }
     constexpr int kPasses = (NN + 17) / 18;
     double tot[kPasses];
@@ -122,26 +131,34 @@ __device__ __forceinline__ void schur_pairs_rows(const Dev& d, int q, int lane, 
 // kernel waits on its gathers) at the price of forming the pair's 2 x 2 core twice: two wavefronts
 // per SIMD, 570 -> 530 us per launch at the Venice shape.  (Three thirds still need 236 registers
 // and ran at 750 us; a 168-register budget spills 69 of them.)
-template <class M, int kSplit>
-__global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d) {
+//
+// kThreads: a workgroup's wavefronts own chunks of very different lengths and its registers and LDS
+// return to the compute unit only when the last one has finished, so small workgroups keep more
+// wavefronts resident (6 x 6: 2.0 -> 2.4 per SIMD on average with one wavefront per workgroup,
+// 155 -> 145 us; 9 x 9: two per workgroup, 384 -> 362 us).
+template <class M, int kSplit, int kThreads>
+__global__ __launch_bounds__(kThreads) void k_schur_pairs(Dev d) {
     constexpr int ND = M::ND;
-    __shared__ __attribute__((aligned(16))) double lds_all[(kBlock / 64) * 64 * 20];
+    __shared__ __attribute__((aligned(16))) double lds_all[(kThreads / 64) * 64 * 20];
     double* lds = lds_all + (threadIdx.x >> 6) * (64 * 20);
     const int lane = threadIdx.x & 63;
-    const int q = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int q = xcd_block(blockIdx.x, gridDim.x) * (kThreads / 64) + (threadIdx.x >> 6);
     if (q >= d.n_pchunks) return;
     if constexpr (kSplit == 1) {
         schur_pairs_rows<M, 0, ND>(d, q, lane, lds);
-    } else if constexpr (kSplit == 2) {
+    } else {
         constexpr int kHalf = (ND + 1) / 2;
         if (blockIdx.y == 0) schur_pairs_rows<M, 0, kHalf>(d, q, lane, lds);
         else schur_pairs_rows<M, kHalf, ND>(d, q, lane, lds);
-    } else {
-        constexpr int kThird = ND / 3;
-        if (blockIdx.y == 0) schur_pairs_rows<M, 0, kThird>(d, q, lane, lds);
-        else if (blockIdx.y == 1) schur_pairs_rows<M, kThird, 2 * kThird>(d, q, lane, lds);
-        else schur_pairs_rows<M, 2 * kThird, ND>(d, q, lane, lds);
     }
+}
+
+// The chunk table as one 16-byte record per chunk (set-up).
+__global__ __launch_bounds__(kBlock) void k_pchunk_records(Dev d, int4* __restrict__ rec) {
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= d.n_pchunks) return;
+    const int blk = d.pchunk_blk[q];
+    rec[q] = make_int4(d.pchunk_beg[q], d.pchunk_beg[q + 1], d.ublk_r[blk], d.ublk_c[blk]);
 }
 
 // Bsum[u][e] = sum over the chunks of upper block u, fixed order.
@@ -334,9 +351,11 @@ int bsr_blocks(const Dev& d) { return cdiv(d.n_cam, kBlock / cam_dim(d)); }
 
 void launch_schur_pairs(const Dev& d, hipStream_t st) {
     if (d.n_pchunks == 0) return;
-    const dim3 grid(cdiv(d.n_pchunks, kBlock / 64));
-    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_schur_pairs<Bal, 2>), dim3(grid.x, 2), dim3(kBlock), 0, st, d);
-    else hipLaunchKernelGGL((k_schur_pairs<Pinhole, 1>), grid, dim3(kBlock), 0, st, d);
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_schur_pairs<Bal, 2, 128>), dim3(cdiv(d.n_pchunks, 2), 2), dim3(128), 0, st, d);
+    else hipLaunchKernelGGL((k_schur_pairs<Pinhole, 1, 64>), dim3(d.n_pchunks), dim3(64), 0, st, d);
+}
+void launch_pchunk_records(const Dev& d, int4* rec, hipStream_t st) {
+    hipLaunchKernelGGL(k_pchunk_records, dim3(cdiv(d.n_pchunks, kBlock)), dim3(kBlock), 0, st, d, rec);
 }
 void launch_block_reduce(const Dev& d, hipStream_t st) {
     const int nn = cam_dim(d) * cam_dim(d);

@@ -258,8 +258,7 @@ __global__ __launch_bounds__(kT) void k_pair_counts(const int* __restrict__ ptr,
 template <bool kOwned>
 __global__ __launch_bounds__(kT) void k_pair_fill(const int* __restrict__ ptr, const int* __restrict__ pt, const int* __restrict__ cam, int n,
                                                   int skip_lo, int skip_hi, const long long* __restrict__ off, unsigned long long n_cam,
-                                                  const int* __restrict__ pm2cm, unsigned long long* __restrict__ keys,
-                                                  int* __restrict__ vals, int* __restrict__ ga, int* __restrict__ gb, int* __restrict__ gp) {
+                                                  unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const int a = blockIdx.x * kT + threadIdx.x;
     if (a >= n) return;
     const int p = pt[a];
@@ -269,16 +268,10 @@ __global__ __launch_bounds__(kT) void k_pair_fill(const int* __restrict__ ptr, c
     for (int b = a + 1; b < b1; ++b) {
         const int cb = cam[b];
         const int lo = min(ca, cb), hi = max(ca, cb);
-        const int first = ca <= cb ? a : b, second = ca <= cb ? b : a;
         const int reps = ca == cb ? 2 : 1;
         for (int r = 0; r < reps; ++r, ++k) {
             keys[k] = (unsigned long long)lo * n_cam + (unsigned long long)hi;
-            if (kOwned) {
-                vals[k] = (int)k;
-                ga[k] = pm2cm[r ? second : first]; gb[k] = pm2cm[r ? first : second]; gp[k] = p;
-            } else {
-                vals[k] = -1;
-            }
+            vals[k] = kOwned ? p : -1;
         }
     }
 }
@@ -301,10 +294,8 @@ __global__ __launch_bounds__(kT) void k_block_flags(const unsigned long long* __
 // Block table and pair lists from the two scans (ublk = blocks before i, kpos = kept before i).
 __global__ __launch_bounds__(kT) void k_block_table(const unsigned long long* __restrict__ keys, const int* __restrict__ vals, size_t m,
                                                     const int* __restrict__ head, const int* __restrict__ ublk, const int* __restrict__ kpos,
-                                                    unsigned long long n_cam, const int* __restrict__ ga, const int* __restrict__ gb,
-                                                    const int* __restrict__ gp, int* __restrict__ ur, int* __restrict__ uc,
-                                                    int* __restrict__ bcount, int* __restrict__ udiag, int* __restrict__ pa,
-                                                    int* __restrict__ pb, int* __restrict__ pp) {
+                                                    unsigned long long n_cam, int* __restrict__ ur, int* __restrict__ uc,
+                                                    int* __restrict__ bcount, int* __restrict__ udiag, int* __restrict__ pp) {
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i > m) return;
     if (i == m) { bcount[ublk[m]] = kpos[m]; return; }
@@ -316,7 +307,7 @@ __global__ __launch_bounds__(kT) void k_block_table(const unsigned long long* __
         if (r == c) udiag[r] = u;
     }
     const int v = vals[i];
-    if (v >= 0) { const int k = kpos[i]; pa[k] = ga[v]; pb[k] = gb[v]; pp[k] = gp[v]; }
+    if (v >= 0) pp[kpos[i]] = v;
 }
 
 // Full block pattern: entry (r, c) of every upper block and, off the diagonal, (c, r); the
@@ -495,20 +486,17 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx) {
 
     const size_t M = (size_t)C + (size_t)n_pairs + (size_t)n_other;
     Arena E(h->ws[2]);
-    E.reserve(2 * Arena::pad(8 * (M + 1)) + 4 * Arena::pad(4 * (M + 1)) + 3 * Arena::pad(4 * ((size_t)n_pairs + 1)) + 16 * 256);
+    E.reserve(2 * Arena::pad(8 * (M + 1)) + 4 * Arena::pad(4 * (M + 1)) + 16 * 256);
     unsigned long long* keys[2] = {E.get<unsigned long long>(M + 1), E.get<unsigned long long>(M + 1)};
     int* vals[2] = {E.get<int>(M + 1), E.get<int>(M + 1)};
-    int* ga = E.get<int>((size_t)n_pairs + 1);
-    int* gb = E.get<int>((size_t)n_pairs + 1);
-    int* gp = E.get<int>((size_t)n_pairs + 1);
     // entries: the diagonal of every camera first (so that every diagonal block exists), this
-    // rank's pairs in point order, then the other ranks' pairs
+    // rank's pairs in point order (value: the point), then the other ranks' pairs (value -1)
     hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(C)), dim3(kT), 0, st, C, keys[0], vals[0]);
     hipLaunchKernelGGL((k_pair_fill<true>), dim3(grid_for(no)), dim3(kT), 0, st, h->pt_ptr.p, h->pm_pt.p, h->pm_cam.p, no, 0, 0, poff,
-                       (unsigned long long)C, pm2cm, keys[0] + C, vals[0] + C, ga, gb, gp);
+                       (unsigned long long)C, keys[0] + C, vals[0] + C);
     if (others) hipLaunchKernelGGL((k_pair_fill<false>), dim3(grid_for(N)), dim3(kT), 0, st, pre, reinterpret_cast<const int*>(spt),
-                                   reinterpret_cast<const int*>(scam), N, pt_lo, pt_lo + np, ooff, (unsigned long long)C, nullptr,
-                                   keys[0] + C + n_pairs, vals[0] + C + n_pairs, nullptr, nullptr, nullptr);
+                                   reinterpret_cast<const int*>(scam), N, pt_lo, pt_lo + np, ooff, (unsigned long long)C,
+                                   keys[0] + C + n_pairs, vals[0] + C + n_pairs);
     sort_pairs(h, keys[0], keys[1], vals[0], vals[1], M, bits_for((uint64_t)C * (uint64_t)C));
     // block starts and kept entries -> block index and pair position of every entry
     int* head = vals[0];                                   // (the unsorted values are no longer needed)
@@ -527,7 +515,7 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx) {
 
     h->ublk_r.alloc((size_t)n_ublk); h->ublk_c.alloc((size_t)n_ublk); h->ublk_diag.alloc((size_t)C);
     h->ublk_chunk_ptr.alloc((size_t)n_ublk + 1); h->ublk_pos.alloc((size_t)n_ublk); h->ublk_pos_t.alloc((size_t)n_ublk);
-    h->pair_a.alloc((size_t)n_pairs); h->pair_b.alloc((size_t)n_pairs); h->pair_p.alloc((size_t)n_pairs);
+    h->pair_p.alloc((size_t)n_pairs);
     const int nnzb = 2 * n_ublk - C;
     h->bsr_ptr.alloc((size_t)C + 1); h->bsr_col.alloc((size_t)nnzb); h->bsr_diag.alloc((size_t)C);
     Arena F(h->ws[4]);
@@ -539,7 +527,7 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx) {
     int* bvals[2] = {F.get<int>(2 * (size_t)n_ublk), F.get<int>(2 * (size_t)n_ublk)};
     unsigned* rows = F.get<unsigned>(2 * (size_t)n_ublk);
     hipLaunchKernelGGL(k_block_table, dim3(grid_for(M + 1)), dim3(kT), 0, st, keys[1], vals[1], M, head, ublk, kpos, (unsigned long long)C,
-                       ga, gb, gp, h->ublk_r.p, h->ublk_c.p, bcount, h->ublk_diag.p, h->pair_a.p, h->pair_b.p, h->pair_p.p);
+                       h->ublk_r.p, h->ublk_c.p, bcount, h->ublk_diag.p, h->pair_p.p);
     // pair chunks of every block
     int pchunk = 512;
     if (const char* e = getenv("SFMBA_PAIR_CHUNK")) { int v = atoi(e); if (v >= 64) pchunk = v; }

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 ARRAYS = ["pt_ptr", "pm_cam", "pm_pt", "pm_orig", "new2old", "cm_pt", "chunk_cam", "chunk_beg", "cam_chunk_ptr", "wtile_beg",
           "ublk_r", "ublk_c", "ublk_chunk_ptr", "ublk_pos", "ublk_pos_t", "ublk_diag", "pchunk_blk", "pchunk_beg",
-          "pair_a", "pair_b", "pair_p", "bsr_ptr", "bsr_col", "bsr_diag"]
+          "pair_p", "bsr_ptr", "bsr_col", "bsr_diag"]
 
 
 def _load(eng, p):
