@@ -26,6 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, GB/s
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector fp64 (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+# fp64 operations of k_schur_pairs<Pinhole> per observation pair, counted in the kernel's ISA (inner
+# loop: 92 v_mul_f64 + 30 v_add_f64 + 100 fused multiply-adds counted twice + 2 v_rcp_f64)
+PAIR_FLOP_PINHOLE = 92 + 30 + 2 * 100 + 2
 
 
 def algorithmic_bytes(n_obs, n_pts, n_cam, n_chunks, n_pairs, n_pair_chunks, cam_dim=6):
@@ -274,6 +278,12 @@ def main():
                               for f in single if f != dom},
             "schur_mode": "explicit" if ps.schur_mode == 2 else "implicit",
             "schur_pairs": int(ps.schur_pairs), "schur_blocks": int(ps.schur_blocks)}
+    if dom == "pairs" and not bal and families[dom]["avg_us"] > 0:
+        # the pair kernel streams little (one index per pair, every point once) and computes much: its
+        # other roof is the vector unit
+        tf = ps.schur_pairs * PAIR_FLOP_PINHOLE / (families[dom]["avg_us"] * 1e-6) / 1e12
+        roof["vector_fp64"] = {"flop_per_pair": PAIR_FLOP_PINHOLE, "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS}
     multi = None
     if world > 1:
         # rank 0's partition and kernels; what does not shrink with the rank count is the PCG on the

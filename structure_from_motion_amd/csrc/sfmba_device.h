@@ -33,6 +33,17 @@ __device__ __forceinline__ double wave_uniform(double v) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// 1 / y by the hardware estimate and two Newton steps (five instructions against the fourteen of
+// an IEEE division; last-bit accuracy, no scaling: |y| must lie well inside the normal range).  For
+// derivative blocks only - residuals and costs use the division (in the observation passes, which
+// wait on memory more than on the vector unit, the division costs nothing measurable).
+__device__ __forceinline__ double newton_rcp(double y) {
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(r, fma(-y, r, 1.0), r);
+    r = fma(r, fma(-y, r, 1.0), r);
+    return r;
+}
+
 // Normalised image coordinates of a point in a camera: x = Y0/Z, y = Y1/Z, iz = 1/Z with the
 // cv2.projectPoints guard (Z == 0 is treated as Z == 1).
 struct Seed { double x, y, iz; };
@@ -46,16 +57,6 @@ __device__ __forceinline__ Seed project_seed(const Cam& k, double X0, double X1,
     s.x = Y0 * s.iz;
     s.y = Y1 * s.iz;
     return s;
-}
-
-// 1 / y by the hardware estimate and two Newton steps (five instructions against the fourteen of
-// an IEEE division; last-bit accuracy, no scaling: |y| must lie well inside the normal range).  For
-// derivative blocks only - residuals and costs use the division.
-__device__ __forceinline__ double newton_rcp(double y) {
-    double r = __builtin_amdgcn_rcp(y);
-    r = fma(r, fma(-y, r, 1.0), r);
-    r = fma(r, fma(-y, r, 1.0), r);
-    return r;
 }
 
 // project_seed with newton_rcp (same guard).
