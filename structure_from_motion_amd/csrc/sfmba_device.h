@@ -610,8 +610,12 @@ template <int N> constexpr int block_reduce_scratch() { return 4 * (72 * N) + 4 
 
 // Sum N per-lane values over the 64 lanes through a per-wave LDS tile instead of log-step
 // shuffles: in passes of H values every lane stores its H values as one row (row stride H+2
-// doubles, 16-byte aligned), then lane e < H adds column e over the 64 rows.  After the call
+// doubles, 16-byte aligned); then P = 64 / H lanes share a column - lane e + k H adds rows k, k + P,
+// k + 2 P, ... of column e - and lane e < H collects the P partial sums.  After the call
 // lane e (< H) holds the totals of values e, H+e, 2H+e, ... in out[0], out[1], ...
+// (One lane per column walked all 64 rows with 64 - H lanes idle: per pass 64 LDS reads and 64
+// additions of a wavefront against 22 + 22 + 6 now, a tenth of the instructions of a 512-observation
+// chunk.)
 // buf: 64*(H+2) doubles owned by this wave.  LDS operations of one wave complete in order, so a
 // wave-level barrier for the compiler plus a wait for outstanding LDS traffic is all the
 // synchronisation the hand-over between lanes needs.
@@ -620,6 +624,9 @@ __device__ __forceinline__ void wave_sum_lds(const double (&acc)[N], double* buf
                                              double (&out)[(N + H - 1) / H]) {
     static_assert(H % 2 == 0, "rows are written as 16-byte pairs");
     constexpr int LD = H + 2;
+    constexpr int P = 64 / H;                    // lanes per column
+    constexpr int R = (64 + P - 1) / P;          // rows per lane (the last one only where it exists)
+    const int part = lane / H, e = lane - part * H;
 #pragma unroll
     for (int p = 0; p < (N + H - 1) / H; ++p) {
         double2* row = reinterpret_cast<double2*>(buf + lane * LD);
@@ -631,15 +638,21 @@ __device__ __forceinline__ void wave_sum_lds(const double (&acc)[N], double* buf
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if (lane < H) {
-            const double* col = buf + lane;
+        if (part < P) {
+            const double* col = buf + part * LD + e;
 #pragma unroll
-            for (int r = 0; r < 64; r += 4) {
-                s0 += col[(r + 0) * LD]; s1 += col[(r + 1) * LD];
-                s2 += col[(r + 2) * LD]; s3 += col[(r + 3) * LD];
+            for (int r = 0; r < R; ++r) {
+                if ((R - 1) * P + P - 1 < 64 || r < R - 1 || part + P * r < 64) {
+                    const double v = col[r * P * LD];
+                    if (r % 4 == 0) s0 += v; else if (r % 4 == 1) s1 += v; else if (r % 4 == 2) s2 += v; else s3 += v;
+                }
             }
         }
-        out[p] = (s0 + s1) + (s2 + s3);
+        double s = (s0 + s1) + (s2 + s3);
+        double tot = s;
+#pragma unroll
+        for (int k = 1; k < P; ++k) tot += __shfl(s, lane + k * H, 64);       // (meaningful in lanes < H)
+        out[p] = tot;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
