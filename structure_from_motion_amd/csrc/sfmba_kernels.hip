@@ -95,8 +95,8 @@ __global__ __launch_bounds__(kBlock) void k_jacobian_blocks(Dev d, double* __res
 // observation beg + l, so every stream is read and written fully coalesced, and per-point sums
 // are segmented reductions over the lanes of a point.
 struct Tile { int beg, end; bool valid, is_long; };
-// consecutive tiles one wavefront of k_lin_pm works through (1, 2, 4, 8 measured: 4 and 8 save 4 % of
-// the kernel by spreading its prologue over more work)
+// consecutive tiles that make one job of k_lin_pm: about fifty points, so that the phase with a lane
+// per point keeps most lanes at work, and 16 KB of LDS per wavefront for the values in between
 constexpr int kTilesPerWave = 4;
 __device__ __forceinline__ Tile wave_tile(const Dev& d, int tpw = 1, int rep = 0) {
     const int q = (xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6)) * tpw + rep;
@@ -157,14 +157,9 @@ __device__ __forceinline__ void damp_point(const Dev& d, int p, const double* Vi
 // s0 = Vinv g_p, what k_damp_pm would otherwise read V and g_p back for.
 // kGrad: only g_p's largest entry and the cost are wanted (the gradient norm at the point a solve
 // ends on): V_p is neither summed nor stored, nothing is damped.
-template <class M, bool kStore, bool kGrad = false>
-__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int keep_v) {
-    __shared__ double red[block_reduce_scratch<2>()];
-    const int lane = threadIdx.x & 63;
-    double cost = 0.0, gmax = 0.0;
-#pragma unroll 1
-    for (int rep = 0; rep < kTilesPerWave; ++rep) {
-    const Tile t = wave_tile(d, kTilesPerWave, rep);
+template <class M, bool kStore, bool kGrad>
+__device__ __forceinline__ void lin_pm_tile_scan(const Dev& d, const Tile& t, int lane, double lambda, int keep_v,
+                                                 double& cost, double& gmax) {
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int key = -1 - lane;
     for (int j = t.beg + lane; j < t.end; j += 64) {
@@ -232,6 +227,192 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
         gmax = fmax(gmax, fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8]))));
         if (lambda > 0.0) damp_point(d, key, acc, acc + 6, lambda);
     }
+}
+
+// What a wavefront of k_lin_pm keeps in LDS between its two phases: per observation of its
+// kTilesPerWave tiles the two rows of the point Jacobian and the residual (value v of slot s at
+// val[v][s], so that the lanes of a store touch consecutive words), and the table of its points
+// (first slot and point index; start[n] = number of slots).
+template <class M>
+struct LinStage {
+    double val[8][64 * kTilesPerWave];
+    double2 cam[kStageCams * M::CW];          // the cameras [c_min, c_min + kStageCams) of the wavefront's observations
+    unsigned short start[64 * kTilesPerWave + 2];
+};
+
+// One job of k_lin_pm: kTilesPerWave consecutive wave tiles, i.e. one range [beg, end) of point-major
+// observations made of whole points, with the coalesced streams of its observations (lane l holds
+// observation beg + 64 r + l in round r).
+struct LinJob {
+    int beg, end;
+    bool any_long;          // holds a tile of more than 64 observations (one long point): done tile by tile
+    int pr[kTilesPerWave], cr[kTilesPerWave];
+    double2 uvr[kTilesPerWave];
+};
+__device__ __forceinline__ LinJob lin_job_fetch(const Dev& d, int jb, int jb_end, int lane, bool streams) {
+    LinJob j;
+    j.beg = j.end = 0;
+    j.any_long = false;
+    if (jb < jb_end) {
+        const int q0 = jb * kTilesPerWave, q1 = min(q0 + kTilesPerWave, d.n_wtiles);
+        j.beg = __builtin_amdgcn_readfirstlane(d.wtile_beg[q0]);
+        j.end = __builtin_amdgcn_readfirstlane(d.wtile_beg[q1]);
+        j.any_long = j.end - j.beg > 64 * (q1 - q0);
+    }
+#pragma unroll
+    for (int r = 0; r < kTilesPerWave; ++r) {
+        const int o = j.beg + 64 * r + lane;
+        j.pr[r] = -2;
+        j.cr[r] = 0x7fffffff;
+        j.uvr[r] = make_double2(0.0, 0.0);
+        if (streams && !j.any_long && o < j.end) {
+            j.pr[r] = d.pm_pt[o];
+            j.cr[r] = d.pm_cam[o];
+            j.uvr[r] = d.pm_uv[o];
+        }
+    }
+    return j;
+}
+
+// The wavefronts of the grid share the jobs evenly (the grid is sized to what the chip holds at once,
+// lin_pm_blocks): wavefront w of W takes jobs [w J / W, (w + 1) J / W), neighbouring wavefronts
+// neighbouring points.  A wavefront works in two phases per job.  Phase one, a lane per
+// observation: projection, residual and point Jacobian go to the wavefront's LDS stage, the first
+// observation of every point enters the point table.  Phase two, a lane per point: the nine sums
+// over the point's observations in their order, then damping, the 3x3 inverse and s0 - every lane
+// at work and no cross-lane traffic (a segmented scan over the lanes of the observations costs four
+// rounds of shuffles for nine values, and only the one lane in five that ends a point then works on
+// the inverse).  The stage leaves two wavefronts per SIMD, so latency is covered inside the
+// wavefront: the index and image-point streams of the next job are requested before this job's
+// arithmetic, and the cameras of a job, which lie in a short index range because points are numbered
+// by their smallest camera, are fetched once per wavefront as one contiguous piece into LDS (a
+// camera outside the piece is gathered).
+template <class M, bool kStore, bool kGrad = false>
+__global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int keep_v) {
+    __shared__ double red[block_reduce_scratch<2>()];
+    __shared__ __attribute__((aligned(16))) LinStage<M> stage_all[kGrad ? 1 : kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    double cost = 0.0, gmax = 0.0;
+    const int n_jobs = (d.n_wtiles + kTilesPerWave - 1) / kTilesPerWave;
+    const int w = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int W = gridDim.x * (kBlock / 64);
+    const int jb0 = (int)((long long)w * n_jobs / W), jb1 = (int)((long long)(w + 1) * n_jobs / W);
+    LinStage<M>& sg = stage_all[kGrad ? 0 : threadIdx.x >> 6];
+    LinJob nx = lin_job_fetch(d, jb0, jb1, lane, !kGrad);
+#pragma unroll 1
+    for (int jb = jb0; jb < jb1; ++jb) {
+        const LinJob cu = nx;
+        if (kGrad || cu.any_long) {
+            nx = lin_job_fetch(d, jb + 1, jb1, lane, !kGrad);
+#pragma unroll 1
+            for (int q = jb * kTilesPerWave; q < min((jb + 1) * kTilesPerWave, d.n_wtiles); ++q) {
+                Tile t;
+                t.valid = true;
+                t.beg = __builtin_amdgcn_readfirstlane(d.wtile_beg[q]);
+                t.end = __builtin_amdgcn_readfirstlane(d.wtile_beg[q + 1]);
+                t.is_long = t.end - t.beg > 64;
+                lin_pm_tile_scan<M, kStore, kGrad>(d, t, lane, lambda, keep_v, cost, gmax);
+            }
+            continue;
+        }
+        const int beg0 = cu.beg, end0 = cu.end;
+        int c0 = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < kTilesPerWave; ++r) c0 = min(c0, cu.cr[r]);
+        c0 = wave_min_int(c0);
+        const int nst = min(kStageCams, d.n_cam - c0);
+        for (int i = lane; i < nst * M::CW; i += 64) sg.cam[i] = d.cams[(size_t)c0 * M::CW + i];
+        double4 Xr[kTilesPerWave];
+#pragma unroll
+        for (int r = 0; r < kTilesPerWave; ++r)
+            if (cu.pr[r] >= 0) Xr[r] = d.X[cu.pr[r]];
+        nx = lin_job_fetch(d, jb + 1, jb1, lane, true);
+        // (the stores to the stage wait for their loads by themselves; the streams of the next job,
+        // requested last, stay in flight through this job's arithmetic)
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        int n_points = 0;
+        int carry = -1;                       // point of the observation before this round's first
+#pragma unroll
+        for (int r = 0; r < kTilesPerWave; ++r) {
+            const int slot = 64 * r + lane;
+            const int j = beg0 + slot;
+            const bool live = j < end0;
+            const int p = cu.pr[r];
+            if (live) {
+                const double4 X = Xr[r];
+                const int rel = cu.cr[r] - c0;
+                const typename M::Cam k = rel < nst ? M::load(sg.cam, rel) : M::load(d.cams, cu.cr[r]);
+                const Seed s = M::seed(k, X.x, X.y, X.z);
+                const typename M::Obs ob = M::obs(s, k, d.K);
+                const double2 uv = cu.uvr[r];
+                double ru, rv;
+                M::residual(ob, uv.x, uv.y, ru, rv);
+                if (kStore) {
+                    d.pm_seed[j] = make_double4(s.x, s.y, s.iz, ru);
+                    d.pm_rv[j] = rv;
+                }
+                double a[3], b[3];
+                M::jac_pt(ob, k.q, a, b);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { sg.val[i][slot] = a[i]; sg.val[3 + i][slot] = b[i]; }
+                sg.val[6][slot] = ru;
+                sg.val[7][slot] = rv;
+                cost += ru * ru + rv * rv;
+            }
+            int prev = __shfl_up(p, 1, 64);
+            if (lane == 0) prev = carry;
+            carry = __shfl(p, 63, 64);
+            const bool first = live && p != prev;
+            const unsigned long long m = __ballot(first);
+            if (first) {
+                const int rank = n_points + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                sg.start[rank] = (unsigned short)slot;
+            }
+            n_points += __builtin_popcountll(m);
+        }
+        if (lane == 0) sg.start[n_points] = (unsigned short)(end0 - beg0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        for (int pp = lane; pp - lane < n_points; pp += 64) {
+            const bool active = pp < n_points;
+            const int s0 = active ? (int)sg.start[pp] : 0;
+            const int len = active ? (int)sg.start[pp + 1] - s0 : 0;
+            const int key = active ? d.pm_pt[beg0 + s0] : 0;
+            double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; __any(k < len); ++k) {
+                if (k < len) {
+                    const int s = s0 + k;
+                    const double a0 = sg.val[0][s], a1 = sg.val[1][s], a2 = sg.val[2][s];
+                    const double b0 = sg.val[3][s], b1 = sg.val[4][s], b2 = sg.val[5][s];
+                    const double ru = sg.val[6][s], rv = sg.val[7][s];
+                    acc[0] += a0 * a0 + b0 * b0;
+                    acc[1] += a0 * a1 + b0 * b1;
+                    acc[2] += a0 * a2 + b0 * b2;
+                    acc[3] += a1 * a1 + b1 * b1;
+                    acc[4] += a1 * a2 + b1 * b2;
+                    acc[5] += a2 * a2 + b2 * b2;
+                    acc[6] += a0 * ru + b0 * rv;
+                    acc[7] += a1 * ru + b1 * rv;
+                    acc[8] += a2 * ru + b2 * rv;
+                }
+            }
+            if (active) {
+                // V_p and g_p themselves are only read back to damp again after a rejected step (and
+                // by the diagnostic entry points): inside a solve they stay in registers and the rare
+                // rejected step linearises again
+                if (keep_v) {
+                    double* Vo = d.V + 6 * (size_t)key;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) Vo[i] = acc[i];
+                    double* go = d.gp + 4 * (size_t)key;
+                    go[0] = acc[6]; go[1] = acc[7]; go[2] = acc[8]; go[3] = 0.0;
+                }
+                gmax = fmax(gmax, fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8]))));
+                if (lambda > 0.0) damp_point(d, key, acc, acc + 6, lambda);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // the next job's stores to the stage stay behind these reads
     }
     static_assert(SLOT_GMAX_PT == SLOT_COST + 1, "slot order");
     const double vals[2] = {cost, gmax};
@@ -979,10 +1160,15 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
     if (d.n_obs == 0) return;
     SFMBA_LAUNCH(d, k_jacobian_blocks, dim3(cdiv(d.n_obs, kBlock)), st, d, jc, jp);
 }
-int lin_pm_blocks(const Dev& d) { return cdiv(d.n_wtiles, (kBlock / 64) * kTilesPerWave); }
+// Grid of k_lin_pm: one wavefront per job while the chip holds them all at once (two workgroups per
+// compute unit, what the LDS stage admits), beyond that the resident wavefronts share the jobs.
+constexpr int kLinPmMaxBlocks = 512;
+int lin_pm_blocks(const Dev& d) { return std::min(cdiv(cdiv(d.n_wtiles, kTilesPerWave), kBlock / 64), kLinPmMaxBlocks); }
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only, bool keep_v, bool defer_scalars) {
     const int kv = keep_v || !(lambda > 0.0) ? 1 : 0;     // undamped: V and g_p are the only products
-    const int nb = cdiv(d.n_wtiles, (kBlock / 64) * kTilesPerWave);
+    // (the gradient-only variant has no LDS stage and fills the chip with a wavefront per job; it is
+    // never deferred, so the count of its block partials is only needed here)
+    const int nb = grad_only ? cdiv(cdiv(d.n_wtiles, kTilesPerWave), kBlock / 64) : lin_pm_blocks(d);
     if (nb > 0 && grad_only) {
         if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_lin_pm<Bal, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0, 0);
         else hipLaunchKernelGGL((k_lin_pm<Pinhole, false, true>), dim3(nb), dim3(kBlock), 0, st, d, 0.0, 0);
