@@ -187,6 +187,7 @@ struct HandleData {
     bool fused_coarse_ok = false;     // structure and sizes admit it
     bool fused_coarse_ready = false;  // an operator has been set up (or is being set up) in this sfmba_solve
     int fused_coarse_from = 12;
+    int fused_prev_iter = 0;           // iterations of the single-launch solve before the last one (0: none yet in this run)
     const double* fused_einv = nullptr;
     bool fused_coarse_wanted = false; // set up an operator beside the next linearisation
     double solve_rtol = 0.0;          // PCG tolerance of the sfmba_solve in progress (0 outside one)

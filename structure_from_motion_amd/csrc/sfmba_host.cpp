@@ -740,6 +740,7 @@ void do_solve(H* h, sfmba_stats* out) {
     st.linear_solver = h->use_dense ? SFMBA_SOLVER_DENSE : SFMBA_SOLVER_PCG;
     h->dense_fallbacks = 0;
     h->fused_solves = h->fused_fallbacks = 0;
+    h->fused_prev_iter = 0;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->coarse_on = h->coarse_forced; h->coarse_failed = false; h->coarse_solves = 0;
     h->fused_coarse_ready = false; h->fused_coarse_wanted = false;
@@ -802,9 +803,18 @@ void do_solve(H* h, sfmba_stats* out) {
                 // the rest of the run (the reduced matrix of the later iterations differs little
                 // from this one: measured, the operator of the iteration before preconditions as
                 // well as the current one) and is renewed when a solve with it grows long again.
-                if (h->fused_coarse_ok && h->fused_pcg &&
-                    ps.iter >= (h->fused.coarse ? 4 * h->fused_coarse_from : h->fused_coarse_from))
-                    h->fused_coarse_wanted = true;
+                // A launch with the correction costs about 40 us before its first iteration and 5
+                // instead of 3 us per iteration for a third to a quarter of the iterations: it pays
+                // from about 40 block-Jacobi iterations, or sooner where the solves of a run grow
+                // (they triple from one to the next while the damping falls; a chain of views with
+                // two-view tracks stays at 20 to 30 and is left alone).
+                if (h->fused_coarse_ok && h->fused_pcg) {
+                    const bool growing = ps.iter >= 2.5 * std::max(h->fused_prev_iter, 1);
+                    if (h->fused.coarse ? ps.iter >= 4 * h->fused_coarse_from
+                                        : ps.iter >= h->fused_coarse_from && (growing || ps.iter >= 40))
+                        h->fused_coarse_wanted = true;
+                }
+                h->fused_prev_iter = ps.iter;
             } else {
                 // breakdown, timeout, or out of iterations with the factorisation at hand: solve
                 // again launch by launch (which knows the dense fallback) and redo the trial step
@@ -1327,13 +1337,44 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     // with 48 and at the Final shape with 128)
     int coarse_k = coarse > 0 ? std::max(coarse, 48) : std::min(128, std::max(48, n_cam / 100));
     coarse_k = std::max(coarse_k, (int)((7LL * n_cam + 4095) / 4096));
+    // Where the single-launch solver will apply the correction itself (k_pcg_pipe2), the vector
+    // kernels' limit does not hold: clusters go down to the eight camera rows of one of its
+    // workgroups, as many of them as its 288 coarse unknowns admit (about 36).  A chain of 47 views
+    // then gets 5 clusters instead of none.
+    const bool fused_small = coarse == 0 && h->fused_pcg && h->cd == 6 && h->fused.pipelined && n_cam < 36 * 48;
+    if (fused_small) {
+        // the smallest size, from the eight rows of a workgroup up, with which the columns of every
+        // workgroup's rows reach at most four clusters (what k_pcg_pipe2 holds of the coarse operator)
+        const int rows = pcg_fused_rows_per_block();
+        coarse_k = std::max(rows, (n_cam + 35) / 36);
+        for (; n_cam / coarse_k >= 2; coarse_k += (coarse_k + 3) / 4) {
+            const int n_cl = n_cam / coarse_k;
+            bool fits = true;
+            for (int b = 0; fits && b * rows < n_cam; ++b) {
+                int list[4], n = 0;
+                for (int r = b * rows; fits && r < std::min(n_cam, (b + 1) * rows); ++r)
+                    for (int e = bsr_ptr[r]; fits && e < bsr_ptr[r + 1]; ++e) {
+                        // cluster i holds cameras [i n_cam / n_cl, (i + 1) n_cam / n_cl)
+                        int J = std::min((int)((int64_t)bsr_col[e] * n_cl / n_cam), n_cl - 1);
+                        while (J > 0 && (int64_t)J * n_cam / n_cl > bsr_col[e]) --J;
+                        while (J + 1 < n_cl && (int64_t)(J + 1) * n_cam / n_cl <= bsr_col[e]) ++J;
+                        bool seen = false;
+                        for (int q = 0; q < n; ++q) seen = seen || list[q] == J;
+                        if (!seen) { if (n < 4) list[n++] = J; else fits = false; }
+                    }
+            }
+            if (fits) break;
+        }
+    }
     // (a single cluster would span the gauge directions of the whole problem and nothing else: S
     // vanishes on them up to the damping, the coarse matrix is rounding noise and the iteration
     // gains nothing; at least two clusters are required)
     h->fused_coarse_ok = false;
     h->fused_coarse_ready = false;
     h->fused_coarse_wanted = false;
-    if (coarse >= 0 && !want_dense && (coarse > 0 || n_cam >= 256) && n_cam / coarse_k >= 2) {
+    // (with two or three such small clusters the correction removes a third of the iterations and
+    // costs more than that: measured on chains of 21 and 47 views)
+    if (coarse >= 0 && !want_dense && (coarse > 0 || n_cam >= 256 || fused_small) && n_cam / coarse_k >= (fused_small ? 4 : 2)) {
         const int k = coarse_k;
         const int n_cl = n_cam / k;
         std::vector<int> cl_ptr((size_t)n_cl + 1), cam_cl((size_t)n_cam);

@@ -178,7 +178,7 @@ def _solve_single_launch(p, monkeypatch, coarse, **opts):
     return first, second, params
 
 
-@pytest.mark.parametrize("n_cam", [300, 700])
+@pytest.mark.parametrize("n_cam", [100, 300, 700])
 def test_single_launch_pcg_with_the_coarse_correction(monkeypatch, n_cam):
     # long camera chains: block-Jacobi needs many iterations late in the run; the coarse operator is
     # set up after the first long solve and used by the solves after it, inside the one launch
@@ -187,18 +187,22 @@ def test_single_launch_pcg_with_the_coarse_correction(monkeypatch, n_cam):
     st, again, (cams1, pts1) = _solve_single_launch(p, monkeypatch, True, ftol=1e-10, pcg_rtol=0.03)
     assert plain.pcg_coarse_solves == 0 and st.pcg_coarse_solves > 0
     assert st.pcg_single_launch == st.iterations and st.pcg_single_fallbacks == 0 and st.pcg_pipelined == 1
-    assert st.pcg_coarse_dim == 7 * (n_cam // 48)
+    # clusters as small as the camera graph lets the kernel hold (at most four among the columns of
+    # a workgroup's rows), at least four and at most 36 of them, seven coarse unknowns each
+    assert st.pcg_coarse_dim % 7 == 0 and 4 * 7 <= st.pcg_coarse_dim <= 36 * 7
     assert st.pcg_iterations < 0.7 * plain.pcg_iterations
     # the same minimum (a preconditioner changes the path of the inexact steps, not where they end)
     assert st.status > 0 and abs(st.final_cost - plain.final_cost) <= 1e-6 * plain.final_cost
-    assert np.abs(pts1 - pts0).max() <= 1e-3
+    # (the points agree up to the free gauge, along which the two runs drift a little differently)
+    assert np.abs(pts1 - pts0).max() <= 1e-2
     # every sum inside the kernel runs in a fixed order and the operator belongs to one iterate
     assert again.final_cost == st.final_cost and again.pcg_iterations == st.pcg_iterations and again.iterations == st.iterations
 
 
 def test_single_launch_coarse_correction_is_skipped_where_its_limits_do_not_hold(monkeypatch):
-    # fewer than 256 cameras: no coarse space at all; the 9-number camera: the kernel is written for 6 x 6 blocks
-    small = syn.make_problem(60, 1500, 8000, seed=22)
+    # too few cameras for four clusters of eight: no coarse space at all; the 9-number camera: the
+    # kernel is written for 6 x 6 blocks
+    small = syn.make_problem(28, 700, 3700, seed=22)
     st, _, _ = _solve_single_launch(small, monkeypatch, True, ftol=1e-10)
     assert st.pcg_coarse_solves == 0 and st.pcg_coarse_dim == 0 and st.pcg_single_launch == st.iterations
     b = _problem("bal", 300, 7500, 39000, seed=23)

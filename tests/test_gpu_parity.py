@@ -419,7 +419,7 @@ def test_both_single_launch_pcg_kernels_agree(monkeypatch):
     out = {}
     for pipe in ("1", "0"):
         monkeypatch.setenv("SFMBA_PCG_PIPE", pipe)
-        with Engine(pcg_mode=2) as eng:
+        with Engine(pcg_mode=2, pcg_coarse=-1) as eng:      # block-Jacobi in both (only the pipelined kernel has a two-level form)
             eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
             out[pipe] = eng.solve()
     a, b = out["1"], out["0"]
