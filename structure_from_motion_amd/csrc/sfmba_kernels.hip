@@ -237,41 +237,81 @@ template <class M>
 struct LinStage {
     double val[8][64 * kTilesPerWave];
     double2 cam[kStageCams * M::CW];          // the cameras [c_min, c_min + kStageCams) of the wavefront's observations
-    unsigned short start[64 * kTilesPerWave + 2];
+    unsigned int start[64 * kTilesPerWave + 2];   // first slot of a point (low 9 bits) and its index less the job's first point
 };
 
 // One job of k_lin_pm: kTilesPerWave consecutive wave tiles, i.e. one range [beg, end) of point-major
-// observations made of whole points, with the coalesced streams of its observations (lane l holds
-// observation beg + 64 r + l in round r).
-struct LinJob {
+// observations made of whole points.  Its operands arrive in two steps, each requested a job ahead of
+// its use: the index streams (lane l holds observation beg + 64 r + l in round r), then what the
+// indices point at.
+struct LinStreams {
     int beg, end;
     bool any_long;          // holds a tile of more than 64 observations (one long point): done tile by tile
     int pr[kTilesPerWave], cr[kTilesPerWave];
-    double2 uvr[kTilesPerWave];
 };
-__device__ __forceinline__ LinJob lin_job_fetch(const Dev& d, int jb, int jb_end, int lane, bool streams) {
-    LinJob j;
+template <class M>
+struct LinGather {
+    double4 X[kTilesPerWave];
+    double2 uv[kTilesPerWave];
+    double2 cam[2];         // words lane and lane + 64 of the cameras [c0, c0 + nst), on their way to the LDS stage
+    int c0, nst;
+};
+static_assert(kStageCams * 8 <= 128, "two words of the camera piece per lane");
+// (Every request below is issued by all lanes, on an index clamped into its array, and the unused
+// results are replaced afterwards: loads inside branches would make the compiler wait for all
+// outstanding loads wherever it waits for one, and the pipeline over the jobs would be gone.)
+// ranges: lane l holds the first observation of job rbase + l (the boundaries of up to 63 jobs, read
+// once per wavefront: a load per job would have to be waited for at once, and with it every request
+// in flight).
+__device__ __forceinline__ int lin_ranges_load(const Dev& d, int rbase, int lane) {
+    return d.wtile_beg[(int)min((long long)(rbase + lane) * kTilesPerWave, (long long)d.n_wtiles)];
+}
+__device__ __forceinline__ LinStreams lin_streams_fetch(const Dev& d, int jb, int jb_end, int lane, bool streams,
+                                                        int ranges, int rbase) {
+    LinStreams j;
     j.beg = j.end = 0;
     j.any_long = false;
     if (jb < jb_end) {
         const int q0 = jb * kTilesPerWave, q1 = min(q0 + kTilesPerWave, d.n_wtiles);
-        j.beg = __builtin_amdgcn_readfirstlane(d.wtile_beg[q0]);
-        j.end = __builtin_amdgcn_readfirstlane(d.wtile_beg[q1]);
+        j.beg = __shfl(ranges, jb - rbase, 64);
+        j.end = __shfl(ranges, jb + 1 - rbase, 64);
+        j.beg = __builtin_amdgcn_readfirstlane(j.beg);
+        j.end = __builtin_amdgcn_readfirstlane(j.end);
         j.any_long = j.end - j.beg > 64 * (q1 - q0);
     }
+    const bool want = streams && !j.any_long;
 #pragma unroll
     for (int r = 0; r < kTilesPerWave; ++r) {
         const int o = j.beg + 64 * r + lane;
-        j.pr[r] = -2;
-        j.cr[r] = 0x7fffffff;
-        j.uvr[r] = make_double2(0.0, 0.0);
-        if (streams && !j.any_long && o < j.end) {
-            j.pr[r] = d.pm_pt[o];
-            j.cr[r] = d.pm_cam[o];
-            j.uvr[r] = d.pm_uv[o];
-        }
+        const int oc = min(o, d.n_obs - 1);
+        const int p = d.pm_pt[oc], c = d.pm_cam[oc];
+        const bool live = want && o < j.end;
+        j.pr[r] = live ? p : -2;
+        j.cr[r] = live ? c : 0x7fffffff;
     }
     return j;
+}
+template <class M>
+__device__ __forceinline__ LinGather<M> lin_gather_fetch(const Dev& d, const LinStreams& j, int lane) {
+    LinGather<M> g;
+    int c0 = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < kTilesPerWave; ++r) c0 = min(c0, j.cr[r]);
+    c0 = wave_min_int(c0);
+    const bool any = c0 != 0x7fffffff;           // (an empty or long job: nothing is used)
+    g.c0 = any ? c0 : 0;
+    g.nst = any ? min(kStageCams, d.n_cam - c0) : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = min(lane + 64 * q, max(g.nst, 1) * M::CW - 1);
+        g.cam[q] = d.cams[(size_t)g.c0 * M::CW + i];
+    }
+#pragma unroll
+    for (int r = 0; r < kTilesPerWave; ++r) {
+        g.X[r] = d.X[max(j.pr[r], 0)];
+        g.uv[r] = d.pm_uv[min(j.beg + 64 * r + lane, d.n_obs - 1)];
+    }
+    return g;
 }
 
 // The wavefronts of the grid share the jobs evenly (the grid is sized to what the chip holds at once,
@@ -283,10 +323,11 @@ __device__ __forceinline__ LinJob lin_job_fetch(const Dev& d, int jb, int jb_end
 // at work and no cross-lane traffic (a segmented scan over the lanes of the observations costs four
 // rounds of shuffles for nine values, and only the one lane in five that ends a point then works on
 // the inverse).  The stage leaves two wavefronts per SIMD, so latency is covered inside the
-// wavefront: the index and image-point streams of the next job are requested before this job's
-// arithmetic, and the cameras of a job, which lie in a short index range because points are numbered
-// by their smallest camera, are fetched once per wavefront as one contiguous piece into LDS (a
-// camera outside the piece is gathered).
+// wavefront by a pipeline over its jobs: while job i is worked on, the points, image points and
+// cameras of job i + 1 and the index streams of job i + 2 are on their way.  The cameras of a job lie
+// in a short index range because points are numbered by their smallest camera: they are fetched
+// once per wavefront as one contiguous piece and handed to the lanes through LDS (a camera outside
+// the piece is gathered).
 template <class M, bool kStore, bool kGrad = false>
 __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int keep_v) {
     __shared__ double red[block_reduce_scratch<2>()];
@@ -296,14 +337,32 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
     const int n_jobs = (d.n_wtiles + kTilesPerWave - 1) / kTilesPerWave;
     const int w = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
     const int W = gridDim.x * (kBlock / 64);
-    const int jb0 = (int)((long long)w * n_jobs / W), jb1 = (int)((long long)(w + 1) * n_jobs / W);
+    const int jb0 = (int)((long long)w * n_jobs / W), jb1_all = (int)((long long)(w + 1) * n_jobs / W);
     LinStage<M>& sg = stage_all[kGrad ? 0 : threadIdx.x >> 6];
-    LinJob nx = lin_job_fetch(d, jb0, jb1, lane, !kGrad);
+    // (the job boundaries of a wavefront fit one register 63 jobs at a time: the pipeline runs over
+    // such stretches; only a wavefront of a very large problem has more than one)
 #pragma unroll 1
-    for (int jb = jb0; jb < jb1; ++jb) {
-        const LinJob cu = nx;
-        if (kGrad || cu.any_long) {
-            nx = lin_job_fetch(d, jb + 1, jb1, lane, !kGrad);
+    for (int rbase = jb0; rbase < jb1_all; rbase += 63) {
+    const int jb1 = min(rbase + 63, jb1_all);
+    const int ranges = lin_ranges_load(d, rbase, lane);
+    LinStreams s1 = lin_streams_fetch(d, rbase, jb1, lane, !kGrad, ranges, rbase);
+    LinStreams s2 = lin_streams_fetch(d, rbase + 1, jb1, lane, !kGrad, ranges, rbase);
+    LinGather<M> g1 = lin_gather_fetch<M>(d, s1, lane);
+#pragma unroll 1
+    for (int jb = rbase; jb < jb1; ++jb) {
+        const LinStreams cu = s1;
+        const LinGather<M> gc = g1;
+        s1 = s2;
+        s2 = lin_streams_fetch(d, jb + 2, jb1, lane, !kGrad, ranges, rbase);
+        g1 = lin_gather_fetch<M>(d, s1, lane);
+        // a point index has to fit beside its slot in a word of the point table (it does unless
+        // millions of unobserved points lie between the points of one job)
+        int p_hi = -1;
+#pragma unroll
+        for (int r = 0; r < kTilesPerWave; ++r) p_hi = max(p_hi, cu.pr[r]);
+        const int p_first = __builtin_amdgcn_readfirstlane(cu.pr[0]);
+        const bool wide = __any(p_hi - p_first >= (1 << 23));
+        if (kGrad || cu.any_long || wide) {
 #pragma unroll 1
             for (int q = jb * kTilesPerWave; q < min((jb + 1) * kTilesPerWave, d.n_wtiles); ++q) {
                 Tile t;
@@ -316,23 +375,18 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
             continue;
         }
         const int beg0 = cu.beg, end0 = cu.end;
-        int c0 = 0x7fffffff;
+        const int c0 = gc.c0, nst = gc.nst;
 #pragma unroll
-        for (int r = 0; r < kTilesPerWave; ++r) c0 = min(c0, cu.cr[r]);
-        c0 = wave_min_int(c0);
-        const int nst = min(kStageCams, d.n_cam - c0);
-        for (int i = lane; i < nst * M::CW; i += 64) sg.cam[i] = d.cams[(size_t)c0 * M::CW + i];
-        double4 Xr[kTilesPerWave];
-#pragma unroll
-        for (int r = 0; r < kTilesPerWave; ++r)
-            if (cu.pr[r] >= 0) Xr[r] = d.X[cu.pr[r]];
-        nx = lin_job_fetch(d, jb + 1, jb1, lane, true);
-        // (the stores to the stage wait for their loads by themselves; the streams of the next job,
-        // requested last, stay in flight through this job's arithmetic)
+        for (int q = 0; q < 2; ++q)
+            if (lane + 64 * q < nst * M::CW) sg.cam[lane + 64 * q] = gc.cam[q];
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
         int n_points = 0;
         int carry = -1;                       // point of the observation before this round's first
+        bool outside = false;                 // some camera of the job lies outside the staged piece
+#pragma unroll
+        for (int r = 0; r < kTilesPerWave; ++r) outside = outside || (cu.pr[r] >= 0 && cu.cr[r] - c0 >= nst);
+        outside = __any(outside);
 #pragma unroll
         for (int r = 0; r < kTilesPerWave; ++r) {
             const int slot = 64 * r + lane;
@@ -340,12 +394,15 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
             const bool live = j < end0;
             const int p = cu.pr[r];
             if (live) {
-                const double4 X = Xr[r];
+                const double4 X = gc.X[r];
                 const int rel = cu.cr[r] - c0;
-                const typename M::Cam k = rel < nst ? M::load(sg.cam, rel) : M::load(d.cams, cu.cr[r]);
+                typename M::Cam k = M::load(sg.cam, min(rel, nst - 1));
+                if (outside) {                  // (wave-uniform: a job whose cameras all lie in the piece has no load here)
+                    if (rel >= nst) k = M::load(d.cams, cu.cr[r]);
+                }
                 const Seed s = M::seed(k, X.x, X.y, X.z);
                 const typename M::Obs ob = M::obs(s, k, d.K);
-                const double2 uv = cu.uvr[r];
+                const double2 uv = gc.uv[r];
                 double ru, rv;
                 M::residual(ob, uv.x, uv.y, ru, rv);
                 if (kStore) {
@@ -367,18 +424,26 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
             const unsigned long long m = __ballot(first);
             if (first) {
                 const int rank = n_points + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                sg.start[rank] = (unsigned short)slot;
+                sg.start[rank] = (unsigned)slot | ((unsigned)(p - p_first) << 9);
             }
             n_points += __builtin_popcountll(m);
         }
-        if (lane == 0) sg.start[n_points] = (unsigned short)(end0 - beg0);
+        if (lane == 0) sg.start[n_points] = (unsigned)(end0 - beg0);
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
-        for (int pp = lane; pp - lane < n_points; pp += 64) {
+        // (written as kTilesPerWave guarded passes, not as a loop: in front of a loop with stores the
+        // compiler waits for every load in flight, the next job's requests among them)
+#pragma unroll
+        for (int pass = 0; pass < kTilesPerWave; ++pass) {
+            if (64 * pass >= n_points) break;
+            const int pp = 64 * pass + lane;
             const bool active = pp < n_points;
-            const int s0 = active ? (int)sg.start[pp] : 0;
-            const int len = active ? (int)sg.start[pp + 1] - s0 : 0;
-            const int key = active ? d.pm_pt[beg0 + s0] : 0;
+            const unsigned word = active ? sg.start[pp] : 0u;
+            const int s0 = (int)(word & 511u);
+            const int len = active ? (int)(sg.start[pp + 1] & 511u) - s0 : 0;
+            // (no load here: it would be younger than the requests for the next job and waiting for
+            // it would wait for all of them)
+            const int key = p_first + (int)(word >> 9);
             double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int k = 0; __any(k < len); ++k) {
                 if (k < len) {
@@ -413,6 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pm(Dev d, double lambda, int kee
             }
         }
         __builtin_amdgcn_wave_barrier();          // the next job's stores to the stage stay behind these reads
+    }
     }
     static_assert(SLOT_GMAX_PT == SLOT_COST + 1, "slot order");
     const double vals[2] = {cost, gmax};
