@@ -677,25 +677,29 @@ __global__ __launch_bounds__(kCmBlock) void k_lin_sdiag_cm(Dev d) {
     // software pipeline: the point index is requested two rounds ahead, the point's X, Vinv, s0 and
     // the observation one round ahead, so that a round's arithmetic overlaps the next round's
     // gathers (two wavefronts per SIMD leave the registers for it)
-    // (Every request is issued by all lanes of a round, on an index clamped into the chunk: behind a
-    // load inside a branch the compiler waits for all loads in flight wherever it waits for one.)
-    const int kf = k0 + lane, kl = k1 - 1;
-    int p1 = d.cm_pt[min(kf, kl)];
-    int p2 = d.cm_pt[min(kf + 64, kl)];
-    double4 nX = d.X[p1], ns0 = d.s0[p1];
-    const double2* vi0 = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p1);
-    double2 n01 = vi0[0], n23 = vi0[1], n45 = vi0[2], nuv = d.cm_uv[min(kf, kl)];
+    const int kf = k0 + lane;
+    int p1 = kf < k1 ? d.cm_pt[kf] : 0;
+    int p2 = kf + 64 < k1 ? d.cm_pt[kf + 64] : 0;
+    double4 nX = make_double4(0.0, 0.0, 0.0, 0.0), ns0 = nX;
+    double2 n01 = make_double2(0.0, 0.0), n23 = n01, n45 = n01, nuv = n01;
+    if (kf < k1) {
+        nX = d.X[p1];
+        const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p1);
+        n01 = vi[0]; n23 = vi[1]; n45 = vi[2];
+        ns0 = d.s0[p1];
+        nuv = d.cm_uv[kf];
+    }
     for (int k = kf; k < k1; k += 64) {
         const double4 X = nX, s0 = ns0;
         const double2 v01 = n01, v23 = n23, v45 = n45, uv = nuv;
         p1 = p2;
-        p2 = d.cm_pt[min(k + 128, kl)];
-        {
+        if (k + 128 < k1) p2 = d.cm_pt[k + 128];
+        if (k + 64 < k1) {
             nX = d.X[p1];
             const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p1);
             n01 = vi[0]; n23 = vi[1]; n45 = vi[2];
             ns0 = d.s0[p1];
-            nuv = d.cm_uv[min(k + 64, kl)];
+            nuv = d.cm_uv[k + 64];
         }
         const Seed s = M::seed(cam, X.x, X.y, X.z);
         const typename M::Obs ob = M::obs(s, cam, d.K);
