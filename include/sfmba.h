@@ -98,7 +98,11 @@ typedef struct sfmba_options {
      *       takes 48 iterations or more.  Launch-per-iteration solver: two more launches per
      *       iteration apply it.  Single-launch solver (pinhole
      *       camera, pipelined form, at most 288 coarse unknowns, rows that reach at most four
-     *       clusters): applied inside the launch;
+     *       clusters): applied inside the launch, and there also below 256 cameras, with
+     *       clusters as small as eight cameras (the smallest size from n_cameras / 36 up with
+     *       which the rows of each of the kernel's workgroups reach at most four clusters; at
+     *       least four clusters), switched on after a solve of 12 iterations or more that took
+     *       2.5 times the iterations of the solve before it, or of 40 or more;
      *  -1 = never;
      *   k > 0 = clusters of k cameras (at least 48; raised where 7 n_cameras / k would exceed 4096),
      *       used from the first solve on, the operator set up from the matrix of every solve in
