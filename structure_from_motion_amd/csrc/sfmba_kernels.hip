@@ -1229,7 +1229,11 @@ void launch_jacobian_blocks(const Dev& d, double* jc, double* jp, hipStream_t st
 // Grid of k_lin_pm: one wavefront per job while the chip holds them all at once (two workgroups per
 // compute unit, what the LDS stage admits), beyond that the resident wavefronts share the jobs.
 constexpr int kLinPmMaxBlocks = 512;
-int lin_pm_blocks(const Dev& d) { return std::min(cdiv(cdiv(d.n_wtiles, kTilesPerWave), kBlock / 64), kLinPmMaxBlocks); }
+int lin_pm_blocks(const Dev& d) {
+    // (SFMBA_LIN_PM_BLOCKS: another cap, for tests of wavefronts with many jobs and for tuning)
+    static const int cap = getenv("SFMBA_LIN_PM_BLOCKS") ? std::max(1, atoi(getenv("SFMBA_LIN_PM_BLOCKS"))) : kLinPmMaxBlocks;
+    return std::min(cdiv(cdiv(d.n_wtiles, kTilesPerWave), kBlock / 64), cap);
+}
 void launch_lin_pm(const Dev& d, bool store_seeds, double lambda, hipStream_t st, bool grad_only, bool keep_v, bool defer_scalars) {
     const int kv = keep_v || !(lambda > 0.0) ? 1 : 0;     // undamped: V and g_p are the only products
     // (the gradient-only variant has no LDS stage and fills the chip with a wavefront per job; it is
