@@ -16,6 +16,9 @@
 #include <cstdlib>
 
 #include "sfmba_internal.h"
+#ifndef SFMBA_BACK_BLOCKS
+#define SFMBA_BACK_BLOCKS 512
+#endif
 
 namespace sfmba {
 
@@ -946,6 +949,206 @@ __device__ __forceinline__ void trial_cost(const Dev& d, const BackObs<M>& o, co
     if (isfinite(e)) cost += e; else bad += 1.0;
 }
 
+// One long tile (a single point with more than 64 observations) of k_back_pm_pipe: the wavefront
+// strides over the observations twice, as k_back_pm does.
+template <class M>
+__device__ __forceinline__ void back_tile_long(const Dev& d, const double* __restrict__ dc, double* __restrict__ dp_out,
+                                               int beg, int end, int lane,
+                                               double& model, double& step2, double& x2, double& trial, double& bad) {
+    double e[3] = {0, 0, 0};
+    const int key = __builtin_amdgcn_readfirstlane(d.pm_pt[beg]);
+    const double4 X = d.X[key];
+    for (int j = beg + lane; j < end; j += 64) {
+        const BackObs<M> o = back_load<M>(d, dc, j, X);
+        M::jpT_times_acc(o.s, o.k.q, o.w0, o.w1, e);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[i] = wave_sum(e[i]);
+    const double4 g = d.s0[key];
+    const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)key);
+    const double2 v01 = vi[0], v23 = vi[1], v45 = vi[2];
+    double dp[3];
+    dp[0] = -(v01.x * e[0] + v01.y * e[1] + v23.x * e[2] + g.x);
+    dp[1] = -(v01.y * e[0] + v23.y * e[1] + v45.x * e[2] + g.y);
+    dp[2] = -(v23.x * e[0] + v45.x * e[1] + v45.y * e[2] + g.z);
+    if (lane == 0) {
+        d.X_trial[key] = make_double4(X.x + dp[0], X.y + dp[1], X.z + dp[2], 0.0);
+        if (dp_out) { dp_out[3 * (size_t)key] = dp[0]; dp_out[3 * (size_t)key + 1] = dp[1]; dp_out[3 * (size_t)key + 2] = dp[2]; }
+        step2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+        x2 += X.x * X.x + X.y * X.y + X.z * X.z;
+    }
+    for (int j = beg + lane; j < end; j += 64) {
+        const BackObs<M> b = back_load<M>(d, dc, j, X);
+        const typename M::Cam kt = M::load(d.cams_trial, b.c);
+        double u0, u1;
+        M::jp_times(b.s, b.k.q, dp, u0, u1);
+        const double l0 = b.ru + b.w0 + u0, l1 = b.rv + b.w1 + u1;
+        model += l0 * l0 + l1 * l1;
+        trial_cost<M>(d, b, kt, X, dp, trial, bad);
+    }
+}
+
+// ---- k_back_pm as a pipeline over the tiles of a resident wavefront -----------------------------
+// What an ordinary tile (one observation per lane) needs arrives in two steps, each requested a
+// tile ahead of its use and by all lanes on clamped indices (see k_lin_pm): the streams of the
+// observations, then what they point at - the point, its damped inverse block and s0, and the
+// tile's cameras [c0, c0 + nst) with their trial versions and steps, which pass through registers
+// into the wavefront's LDS stage.
+struct BackStreams {
+    int beg, end;
+    bool is_long;
+    int key, c;
+    double2 uv;
+};
+template <class M>
+struct BackGather {
+    double4 X, g;
+    double2 v01, v23, v45;
+    double2 cam[2], trial[2];
+    double dcr[3];
+    int c0, nst;
+};
+static_assert(kStageCams * 9 <= 192 && kStageCams * 8 <= 128, "stage pieces per lane");
+__device__ __forceinline__ BackStreams back_streams_fetch(const Dev& d, int q, int q_end, int lane, int ranges, int rbase) {
+    BackStreams t;
+    t.beg = t.end = 0;
+    if (q < q_end) {
+        t.beg = __builtin_amdgcn_readfirstlane(__shfl(ranges, q - rbase, 64));
+        t.end = __builtin_amdgcn_readfirstlane(__shfl(ranges, q + 1 - rbase, 64));
+    }
+    t.is_long = t.end - t.beg > 64;
+    const int j = t.beg + lane;
+    const int jc = min(j, d.n_obs - 1);
+    const int key = d.pm_pt[jc], c = d.pm_cam[jc];
+    t.uv = d.pm_uv[jc];
+    const bool live = !t.is_long && j < t.end;
+    t.key = live ? key : -1 - lane;
+    t.c = live ? c : 0x7fffffff;
+    return t;
+}
+template <class M>
+__device__ __forceinline__ BackGather<M> back_gather_fetch(const Dev& d, const double* __restrict__ dc, const BackStreams& t, int lane) {
+    BackGather<M> g;
+    const int c0 = wave_min_int(t.c);
+    const bool any = c0 != 0x7fffffff;
+    g.c0 = any ? c0 : 0;
+    g.nst = any ? min(kStageCams, d.n_cam - c0) : 0;
+    const int ncw = max(g.nst, 1) * M::CW, nd = max(g.nst, 1) * M::ND;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = min(lane + 64 * q, ncw - 1);
+        g.cam[q] = d.cams[(size_t)g.c0 * M::CW + i];
+        g.trial[q] = d.cams_trial[(size_t)g.c0 * M::CW + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) g.dcr[q] = dc[(size_t)g.c0 * M::ND + min(lane + 64 * q, nd - 1)];
+    const int p = max(t.key, 0);
+    g.X = d.X[p];
+    g.g = d.s0[p];
+    const double2* vi = reinterpret_cast<const double2*>(d.Vinv + 6 * (size_t)p);
+    g.v01 = vi[0]; g.v23 = vi[1]; g.v45 = vi[2];
+    return g;
+}
+// tiles of one register of boundaries (63) per stretch; grid: what the chip holds at once
+constexpr int kBackMaxBlocks = SFMBA_BACK_BLOCKS;
+
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_back_pm_pipe(Dev d, const double* __restrict__ dc, double* __restrict__ dp_out) {
+    __shared__ double red[block_reduce_scratch<5>()];
+    __shared__ __attribute__((aligned(16))) CamStage<M> stage[kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    double model = 0.0, step2 = 0.0, x2 = 0.0, trial = 0.0, bad = 0.0;
+    const int w = xcd_block(blockIdx.x, gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int W = gridDim.x * (kBlock / 64);
+    const int t0 = (int)((long long)w * d.n_wtiles / W), t1_all = (int)((long long)(w + 1) * d.n_wtiles / W);
+    CamStage<M>& sg = stage[threadIdx.x >> 6];
+#pragma unroll 1
+    for (int rbase = t0; rbase < t1_all; rbase += 63) {
+    const int t1 = min(rbase + 63, t1_all);
+    const int ranges = d.wtile_beg[min(rbase + lane, d.n_wtiles)];
+    BackStreams s1 = back_streams_fetch(d, rbase, t1, lane, ranges, rbase);
+    BackStreams s2 = back_streams_fetch(d, rbase + 1, t1, lane, ranges, rbase);
+    BackGather<M> g1 = back_gather_fetch<M>(d, dc, s1, lane);
+#pragma unroll 1
+    for (int q = rbase; q < t1; ++q) {
+        const BackStreams cu = s1;
+        const BackGather<M> gc = g1;
+        s1 = s2;
+        s2 = back_streams_fetch(d, q + 2, t1, lane, ranges, rbase);
+        g1 = back_gather_fetch<M>(d, dc, s1, lane);
+        if (cu.is_long) {
+            back_tile_long<M>(d, dc, dp_out, cu.beg, cu.end, lane, model, step2, x2, trial, bad);
+            continue;
+        }
+        // the tile's cameras into the stage
+        const int c0 = gc.c0, nst = gc.nst;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (lane + 64 * k < nst * M::CW) { sg.cam[lane + 64 * k] = gc.cam[k]; sg.trial[lane + 64 * k] = gc.trial[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (lane + 64 * k < nst * M::ND) sg.dc[lane + 64 * k] = gc.dcr[k];
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        const int key = cu.key;
+        const bool live = key >= 0;
+        const bool outside = __any(live && cu.c - c0 >= nst);
+        BackObs<M> o{};
+        typename M::Cam kt{};
+        const double4 X = gc.X;
+        double e[3] = {0, 0, 0};
+        if (live) {
+            o.uv = cu.uv;
+            o.c = cu.c;
+            const int rel = min(cu.c - c0, nst - 1);
+            double dd[M::ND];
+            o.k = M::load(sg.cam, rel);
+            kt = M::load(sg.trial, rel);
+#pragma unroll
+            for (int i = 0; i < M::ND; ++i) dd[i] = sg.dc[M::ND * rel + i];
+            if (outside) {                      // (wave-uniform: a tile whose cameras all lie in the piece has no load here)
+                if (cu.c - c0 >= nst) {
+                    o.k = M::load(d.cams, cu.c);
+                    kt = M::load(d.cams_trial, cu.c);
+                    load_tangent<M::ND>(dc, cu.c, dd);
+                }
+            }
+            back_finish<M>(d, o, dd, X);
+            M::jpT_times_acc(o.s, o.k.q, o.w0, o.w1, e);
+        }
+        seg_scan(e, key, lane);
+        const int last = seg_last(key, lane);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e[i] = __shfl(e[i], last, 64);
+        const bool writer = live && last == lane;
+        double dp[3] = {0, 0, 0};
+        if (live) {
+            // g holds V*^-1 g_p
+            dp[0] = -(gc.v01.x * e[0] + gc.v01.y * e[1] + gc.v23.x * e[2] + gc.g.x);
+            dp[1] = -(gc.v01.y * e[0] + gc.v23.y * e[1] + gc.v45.x * e[2] + gc.g.y);
+            dp[2] = -(gc.v23.x * e[0] + gc.v45.x * e[1] + gc.v45.y * e[2] + gc.g.z);
+        }
+        if (writer) {
+            d.X_trial[key] = make_double4(X.x + dp[0], X.y + dp[1], X.z + dp[2], 0.0);
+            if (dp_out) { dp_out[3 * (size_t)key] = dp[0]; dp_out[3 * (size_t)key + 1] = dp[1]; dp_out[3 * (size_t)key + 2] = dp[2]; }
+            step2 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+            x2 += X.x * X.x + X.y * X.y + X.z * X.z;
+        }
+        if (live) {
+            double u0, u1;
+            M::jp_times(o.s, o.k.q, dp, u0, u1);
+            const double l0 = o.ru + o.w0 + u0, l1 = o.rv + o.w1 + u1;
+            model += l0 * l0 + l1 * l1;
+            trial_cost<M>(d, o, kt, X, dp, trial, bad);
+        }
+        __builtin_amdgcn_wave_barrier();          // the next tile's stores to the stage stay behind these reads
+    }
+    }
+    const double vals[5] = {model, step2, x2, trial, bad};
+    const double r = block_reduce_n<5>(vals, 0u, red);
+    if (threadIdx.x < 5) put_partial(d, SLOT_MODEL + threadIdx.x, r);
+}
+
 template <class M, bool kStage>
 __global__ __launch_bounds__(kBlock) void k_back_pm(Dev d, const double* __restrict__ dc,
                                                     double* __restrict__ dp_out) {
@@ -1297,14 +1500,19 @@ void launch_schur_apply(const Dev& d, const double* x, double lambda, double* y,
     SFMBA_LAUNCH(d, k_schur_apply, dim3(blocks_cam(d)), st, d, x, lambda, y);
 }
 void launch_back_pm(const Dev& d, const double* dc, double* dp_out, hipStream_t st, bool with_lin_scalars) {
-    const int nb = blocks_wtile(d);
-    static const bool stage = !(getenv("SFMBA_STAGE_CAMS") && atoi(getenv("SFMBA_STAGE_CAMS")) == 0);
+    // SFMBA_BACK_PM: 2 (default) the pipeline over resident wavefronts, 1 a wavefront per tile with
+    // the cameras staged in LDS, 0 a wavefront per tile with every camera gathered
+    static const int mode = getenv("SFMBA_BACK_PM") ? atoi(getenv("SFMBA_BACK_PM")) : 2;
+    static const int cap = getenv("SFMBA_BACK_PM_BLOCKS") ? std::max(1, atoi(getenv("SFMBA_BACK_PM_BLOCKS"))) : kBackMaxBlocks;
+    const int nb = mode == 2 ? std::min(blocks_wtile(d), cap) : blocks_wtile(d);
     if (nb <= 0) return;
-    if (d.model == MODEL_BAL) {
-        if (stage) hipLaunchKernelGGL((k_back_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
+    if (mode == 2) {
+        SFMBA_LAUNCH(d, k_back_pm_pipe, dim3(nb), st, d, dc, dp_out);
+    } else if (d.model == MODEL_BAL) {
+        if (mode == 1) hipLaunchKernelGGL((k_back_pm<Bal, true>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
         else hipLaunchKernelGGL((k_back_pm<Bal, false>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
     } else {
-        if (stage) hipLaunchKernelGGL((k_back_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
+        if (mode == 1) hipLaunchKernelGGL((k_back_pm<Pinhole, true>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
         else hipLaunchKernelGGL((k_back_pm<Pinhole, false>), dim3(nb), dim3(kBlock), 0, st, d, dc, dp_out);
     }
     // MODEL .. NONFINITE, and with them the two slots k_cam_update left as block partials
