@@ -430,32 +430,49 @@ def test_both_single_launch_pcg_kernels_agree(monkeypatch):
     assert abs(a.final_cost - b.final_cost) <= 1e-10 * b.final_cost
 
 
-def test_point_major_linearisation_with_many_jobs_per_wavefront():
-    # k_lin_pm hands the job boundaries of a wavefront out of one register, 63 jobs at a time; only a
-    # problem of tens of millions of observations gives a wavefront more than that with the default
-    # grid, so the grid is capped here (the cap is read once per process: a child process)
-    import subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import json, sys
-        from structure_from_motion_amd import synthetic as syn
-        from structure_from_motion_amd.engine import Engine
-        p = syn.make_shape("venice", seed=5, scale=0.05)
-        with Engine() as eng:
-            eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
-            st = eng.solve()
-            cams, pts = eng.get_params()
-        print(json.dumps(dict(cost=st.final_cost, it=st.iterations, pcg=st.pcg_iterations, c0=float(cams[3, 10]), x0=float(pts[17, 1]))))
-    """)
-    import json, os
-    out = {}
-    for cap in ("512", "1"):
-        env = dict(os.environ, SFMBA_LIN_PM_BLOCKS=cap)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120,
-                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0, r.stderr[-2000:]
-        out[cap] = json.loads(r.stdout.strip().splitlines()[-1])
-    a, b = out["512"], out["1"]
-    # the same sums per point in the same order; only the cost's partial sums are grouped differently
-    assert a["it"] == b["it"] and abs(a["pcg"] - b["pcg"]) <= 2
-    assert abs(a["cost"] - b["cost"]) <= 1e-12 * a["cost"]
-    assert abs(a["c0"] - b["c0"]) <= 1e-10 and abs(a["x0"] - b["x0"]) <= 1e-10
+_VARIANT_CODE = """
+import json, sys
+sys.path.insert(0, "tests")
+from structure_from_motion_amd import synthetic as syn
+from structure_from_motion_amd.engine import Engine
+from test_gpu_irregular import irregular_problem
+out = []
+for p in (syn.make_shape("venice", seed=5, scale=0.05), irregular_problem(3)):
+    with Engine() as eng:
+        eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
+        st = eng.solve()
+        cams, pts = eng.get_params()
+    out.append(dict(cost=st.final_cost, it=st.iterations, pcg=st.pcg_iterations, c0=float(cams[3, 10]), x0=float(pts[17, 1])))
+print(json.dumps(out))
+"""
+
+
+def _solve_in_child(env_extra):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CODE], env=dict(os.environ, **env_extra), capture_output=True,
+                       text=True, timeout=180, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope="module")
+def default_variant():
+    return _solve_in_child({})
+
+
+@pytest.mark.parametrize("env", [{"SFMBA_LIN_PM_BLOCKS": "1"}, {"SFMBA_BACK_PM_BLOCKS": "1"}, {"SFMBA_BACK_PM": "1"},
+                                 {"SFMBA_BACK_PM": "0"}], ids=lambda e: "-".join(f"{k}={v}" for k, v in e.items()))
+def test_forms_of_the_point_major_passes_agree(default_variant, env):
+    # The pipelined point-major passes hand a wavefront's job / tile boundaries out of one register,
+    # 63 at a time; only a problem of tens of millions of observations gives a wavefront more than
+    # that with the default grids, so the grids are capped here.  The back-substitution also keeps
+    # its two earlier forms (a wavefront per tile, cameras staged or gathered).  All of them form the
+    # same sums per point in the same order; the scalar sums over the workgroups are grouped
+    # differently.  (The switches are read once per process: child processes.)  Two problems: a
+    # scaled Venice shape and the irregular one (long tracks, single observations, duplicates).
+    got = _solve_in_child(env)
+    for a, b in zip(default_variant, got):
+        assert a["it"] == b["it"] and abs(a["pcg"] - b["pcg"]) <= 2
+        assert abs(a["cost"] - b["cost"]) <= 1e-11 * a["cost"]
+        assert abs(a["c0"] - b["c0"]) <= 1e-9 and abs(a["x0"] - b["x0"]) <= 1e-9
