@@ -1,3 +1,5 @@
+"""Wall time and Python profile of a whole BundleAdjustment.optimize() on the 47-view temple-ring chain
+(study script, GPU box): python profiles/study_optimize_overheads.py"""
 import sys, time, cProfile, pstats, os, tempfile
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np, pandas as pd

@@ -1,3 +1,5 @@
+"""Temple-ring chains run to convergence by SciPy (ftol = xtol = 1e-15, 400 evaluations) and by the engine
+(study script, GPU box): python profiles/study_temple_tight.py"""
 import sys, time
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.'); sys.path.insert(0, 'profiles')
 from study_forcing_term import temple
