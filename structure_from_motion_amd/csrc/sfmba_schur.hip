@@ -275,30 +275,47 @@ __global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const 
 // k_finish_offdiag, one thread per element of every upper off-diagonal block: both orientations
 // of the block in the full matrix and, for the single-launch PCG, of the scaled block
 // F_r S_rc F_c' (its transpose is the scaled S_cr).
+// A workgroup takes kBlock / NN whole blocks: a thread's own element of B goes through LDS to the
+// others of its block, t = B F_c' is formed once per block (NN short sums instead of one per
+// thread and row), and every thread finishes its element of F_r t.  (One thread per element that
+// read all of B and both rows of F itself: 16 us per launch at the Venice shape, now 11.)
 template <int ND>
 __global__ __launch_bounds__(kBlock) void k_finish_offdiag(Dev d, FusedPcg f) {
-    constexpr int NN = ND * ND;
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= d.n_ublk * NN) return;
-    const int u = t / NN, e = t - NN * u, i = e / ND, j = e - ND * i;
-    const int r = d.ublk_r[u], c = d.ublk_c[u];
-    if (r == c) return;
-    const size_t pos = NN * (size_t)d.ublk_pos[u] + e, pos_t = NN * (size_t)d.ublk_pos_t[u] + ND * j + i;
-    const double v = -d.Bsum[t];
-    d.Sfull[pos] = v;
-    d.Sfull[pos_t] = v;
+    constexpr int NN = ND * ND, kPer = kBlock / NN;
+    __shared__ double sB[kPer][NN], sT[kPer][NN];
+    const int lb = threadIdx.x / NN, e = threadIdx.x - NN * lb, i = e / ND, j = e - ND * i;
+    const int u = blockIdx.x * kPer + lb;
+    const bool act = lb < kPer && u < d.n_ublk;
+    int r = 0, c = 0;
+    if (act) {
+        r = d.ublk_r[u]; c = d.ublk_c[u];
+        sB[lb][e] = d.Bsum[NN * (size_t)u + e];
+    }
+    __syncthreads();
+    const bool off = act && r != c;
+    size_t pos = 0, pos_t = 0;
+    if (off) {
+        pos = NN * (size_t)d.ublk_pos[u] + e;
+        pos_t = NN * (size_t)d.ublk_pos_t[u] + ND * j + i;
+        const double v = -sB[lb][e];
+        d.Sfull[pos] = v;
+        d.Sfull[pos_t] = v;
+    }
     if (f.F == nullptr) return;
-    const double* Fi = f.F + NN * (size_t)r + ND * i;
-    const double* Fj = f.F + NN * (size_t)c + ND * j;
-    const double* B = d.Bsum + NN * (size_t)u;
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < ND; ++k) {
+    if (off) {
+        // t[i][j] = sum_l B[i][l] F_c[j][l]
+        const double* Fj = f.F + NN * (size_t)c + ND * j;
         double tk = 0.0;
 #pragma unroll
-        for (int l = 0; l < ND; ++l) tk += B[ND * k + l] * Fj[l];
-        s += Fi[k] * tk;
+        for (int l = 0; l < ND; ++l) tk += sB[lb][ND * i + l] * Fj[l];
+        sT[lb][e] = tk;
     }
+    __syncthreads();
+    if (!off) return;
+    const double* Fi = f.F + NN * (size_t)r + ND * i;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) s += Fi[k] * sT[lb][ND * k + j];
     double* H = const_cast<double*>(f.Shat);
     H[pos] = -s;
     H[pos_t] = -s;
@@ -369,11 +386,11 @@ void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const
     if (d.model == MODEL_BAL) {
         hipLaunchKernelGGL((k_finish_diag<Bal>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f);
         if (d.n_ublk > 0)
-            hipLaunchKernelGGL((k_finish_offdiag<Bal::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
+            hipLaunchKernelGGL((k_finish_offdiag<Bal::ND>), dim3(cdiv(d.n_ublk, kBlock / nn)), dim3(kBlock), 0, st, d, f);
     } else {
         hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f);
         if (d.n_ublk > 0)
-            hipLaunchKernelGGL((k_finish_offdiag<Pinhole::ND>), dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, f);
+            hipLaunchKernelGGL((k_finish_offdiag<Pinhole::ND>), dim3(cdiv(d.n_ublk, kBlock / nn)), dim3(kBlock), 0, st, d, f);
     }
 }
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st) {
