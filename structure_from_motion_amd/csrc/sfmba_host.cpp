@@ -1272,9 +1272,9 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     }
     HIP_TRY(hipStreamSynchronize(st));
     h->explicit_schur = true;
-    // one camera-major pass per linearisation instead of two (k_lin_sdiag_cm): measured for the
-    // 6-number camera; the 9-number camera would carry 72 running sums per lane
-    h->fuse_cm = h->model == MODEL_PINHOLE;
+    // one camera-major pass per linearisation instead of two (k_lin_sdiag_cm): 2 % of a solve with
+    // the 6-number camera and, its 72 running sums per lane notwithstanding, with the 9-number one
+    h->fuse_cm = true;
     if (const char* e = getenv("SFMBA_FUSE_CM")) h->fuse_cm = atoi(e) != 0;
     h->cm_lambda = -1.0;
     // single-launch PCG: one workgroup per compute unit at most, every workgroup co-resident
