@@ -61,7 +61,7 @@ typedef struct sfmba_options {
     int32_t max_nfev;
     /* Levenberg-Marquardt / linear solver controls (no counterpart in the reference). */
     int32_t max_iterations;   /* cap on LM iterations (accepted + rejected); 0 = 200 */
-    double initial_lambda;    /* initial damping; 0 = 1e-4 */
+    double initial_lambda;    /* initial damping; 0 = chosen by the library: 1e-4, or 1e-10 where the camera system is factored exactly */
     double pcg_rtol;          /* PCG stops at sqrt(r'M^-1 r / r0'M^-1 r0) <= pcg_rtol; 0 = choose: 0.03 where the
                                  single-launch solver runs (its iterations are cheap), 0.1 otherwise */
     int32_t pcg_max_iter;     /* 0 = 1000 */

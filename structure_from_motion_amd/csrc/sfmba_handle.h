@@ -196,8 +196,11 @@ struct HandleData {
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
     bool dense_allowed = false;  // small enough for the dense fallback
+    bool dense_auto = false;     // dense Cholesky chosen by the library (small system): exact steps, damping from its floor
     int dense_n = 0;
     DBuf<double> denseA, denseLinv, denseWork;
+    DBuf<double> denseFlow;      // tiles and exchange words of the single-launch factorisation
+    bool dense_flow = false;     // the single-launch factorisation is used (small systems)
     DBuf<int> dense_fail;
     int dense_fallbacks = 0;
     int cur = 0;                           // index of the current parameter buffers

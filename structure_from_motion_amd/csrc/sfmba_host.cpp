@@ -599,14 +599,42 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
 
 // Dense path: scatter S into a dense array, factor it on the matrix cores, solve for the camera
 // step.  Returns false when a pivot was not positive (caller falls back to PCG).
+// The single-launch factorisation (sfmba_chol.hip) serves systems up to this many unknowns: one
+// workgroup per 32 rows, all of them resident at once.
+constexpr int kDenseFlowMax = 1536;
+
+// Buffers of the dense solver for the problem at hand (a handle outlives its problems, and the
+// next one may have more cameras).
+void ensure_dense(H* h) {
+    const int need = dense_padded(h->cd * (int)h->n_cam);
+    h->dense_n = need;
+    h->denseA.alloc((size_t)need * need);
+    h->denseLinv.alloc((size_t)need * 32);
+    h->denseWork.alloc((size_t)need * 2);
+    h->dense_fail.alloc(1);
+    h->dense_flow = need <= kDenseFlowMax;
+    if (const char* e = getenv("SFMBA_DENSE_FLOW")) h->dense_flow = h->dense_flow && atoi(e) != 0;
+    if (h->dense_flow) h->denseFlow.alloc(chol_flow_words(need));
+}
+
 bool phase_dense(H* h) {
     Scope t(h, F_DENSE);
     const int n = h->dense_n, n_real = h->cd * (int)h->n_cam;
     h->denseA.zero(h->stream);
-    h->dense_fail.zero(h->stream);
     launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
-    launch_dense_cholesky_solve(h->denseA.p, n, n_real, h->denseLinv.p, h->denseWork.p, h->dense_fail.p, h->rhs.p, h->px.p, h->stream);
     int failed = 0;
+    if (h->dense_flow) {
+        HIP_TRY(launch_chol_flow(h->denseA.p, n, n_real, h->rhs.p, h->px.p, h->denseFlow.p, h->dense_fail.p, nullptr, nullptr, h->stream));
+        HIP_TRY(hipMemcpyAsync(&failed, h->dense_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (failed != 2) return failed == 0;
+        // given up (time limit: the workgroups were not resident together): the chain of launches
+        h->dense_flow = false;
+        h->denseA.zero(h->stream);
+        launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
+    }
+    h->dense_fail.zero(h->stream);
+    launch_dense_cholesky_solve(h->denseA.p, n, n_real, h->denseLinv.p, h->denseWork.p, h->dense_fail.p, h->rhs.p, h->px.p, h->stream);
     HIP_TRY(hipMemcpyAsync(&failed, h->dense_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return failed == 0;
@@ -619,17 +647,14 @@ int phase_linear_solve(H* h, double lambda, bool allow_fused = true) {
     if (h->use_dense) {
         if (phase_dense(h)) return 0;
         h->dense_fallbacks++;
+        // (chosen by the library: the matrix is not positive definite to working precision at this
+        // damping, which the caller raises)
+        if (h->dense_auto) return -1;
     }
     const PcgState st = phase_pcg(h, lambda, allow_fused);
     const bool converged = !(st.rz > st.tol2 * st.rz0);
     if (!converged && !h->use_dense && h->dense_allowed && h->explicit_schur) {
-        if (h->denseA.n == 0) {
-            h->dense_n = dense_padded(h->cd * (int)h->n_cam);
-            h->denseA.alloc((size_t)h->dense_n * h->dense_n);
-            h->denseLinv.alloc((size_t)h->dense_n * 32);
-            h->denseWork.alloc((size_t)h->dense_n * 2);
-            h->dense_fail.alloc(1);
-        }
+        if (h->dense_n != dense_padded(h->cd * (int)h->n_cam)) ensure_dense(h);
         h->dense_fallbacks++;
         if (phase_dense(h)) return st.iter;
         // factorisation failed too: keep the PCG iterate (it is a descent direction)
@@ -734,7 +759,12 @@ void do_solve(H* h, sfmba_stats* out) {
     const int64_t n_par = (h->model == MODEL_BAL ? 9 : 12) * h->n_cam + 3 * h->n_pts_all;
     const int64_t max_nfev = o.max_nfev > 0 ? o.max_nfev : 100 * n_par;
     const int max_it = o.max_iterations > 0 ? o.max_iterations : 200;
-    double lambda = o.initial_lambda > 0 ? o.initial_lambda : 1e-4;
+    // Damping: 1e-4 of the scaling to begin with where the camera system is solved by PCG; where it is
+    // factored (exact steps) it starts at its floor, i.e. with Gauss-Newton steps, and a step that
+    // fails sends it to the 1e-4 of the other case.
+    const bool exact_steps = h->use_dense && h->dense_auto;
+    const double lambda_floor = h->use_dense ? 1e-12 : 1e-15;
+    double lambda = o.initial_lambda > 0 ? o.initial_lambda : exact_steps ? 1e-10 : 1e-4;
     double nu = 2.0;
     sfmba_stats st{};
     st.linear_solver = h->use_dense ? SFMBA_SOLVER_DENSE : SFMBA_SOLVER_PCG;
@@ -774,7 +804,13 @@ void do_solve(H* h, sfmba_stats* out) {
         phase_damp(h, lambda);
         const bool pending = launch_linear_solve_async(h);
         if (!pending) {
-            st.pcg_iterations += phase_linear_solve(h, lambda);
+            const int its = phase_linear_solve(h, lambda);
+            if (its < 0) {
+                lambda = std::max(16.0 * lambda, 1e-8);
+                if (lambda > 1e32) status = SFMBA_STATUS_XTOL;
+                continue;
+            }
+            st.pcg_iterations += its;
             HIP_TRY(hipMemsetAsync(h->scalars.p + SLOT_PCGFLAG, 0, sizeof(double), h->stream));
         }
         phase_trial(h, nullptr);
@@ -841,7 +877,7 @@ void do_solve(H* h, sfmba_stats* out) {
         if (rho > 1e-3) {
             h->cur ^= 1;
             ++accepted;
-            lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-15);
+            lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), lambda_floor);
             nu = 2.0;
             cost = cost_new;
             // also the gradient norm at the new iterate; damps for the next step, unless this was the last
@@ -855,7 +891,7 @@ void do_solve(H* h, sfmba_stats* out) {
             else if (xt) status = SFMBA_STATUS_XTOL;
             else if (!lin_pending && g_norm < gtol) status = SFMBA_STATUS_GTOL;
         } else {
-            lambda *= nu;
+            lambda = exact_steps && lambda < 1e-4 / nu ? 1e-4 : lambda * nu;
             nu *= 2.0;
             if (xt || lambda > 1e32) status = SFMBA_STATUS_XTOL;
         }
@@ -1043,8 +1079,15 @@ SchurPlan sfmba::plan_schur(H* h) {
     int lin = h->opt.linear_solver;
     if (const char* e = getenv("SFMBA_LINEAR_SOLVER")) lin = atoi(e);
     const int dense_max = h->opt.dense_max_dim > 0 ? h->opt.dense_max_dim : 1536;
-    const bool want_dense = lin == SFMBA_SOLVER_DENSE;
     const int64_t n_red = (int64_t)h->cd * h->n_cam;       // unknowns of the reduced system
+    // Left to choose, a small camera system is factored (one launch, sfmba_chol.hip) rather than
+    // iterated on: the reference's own workloads (11 views, a ring of 47) have 66 to 282 unknowns,
+    // an exact step lets the damping fall to its floor, and the Gauss-Newton steps that follow are
+    // what SciPy's trust-region solver takes on them (scipy/optimize/_lsq/trf.py:473-499).
+    int auto_dense_dim = 320;
+    if (const char* e = getenv("SFMBA_DENSE_AUTO_DIM")) auto_dense_dim = atoi(e);
+    h->dense_auto = lin == SFMBA_SOLVER_AUTO && mode != 1 && dense_padded((int)std::min<int64_t>(n_red, 1 << 20)) <= auto_dense_dim;
+    const bool want_dense = lin == SFMBA_SOLVER_DENSE || h->dense_auto;
     h->dense_allowed = lin == SFMBA_SOLVER_AUTO && n_red <= dense_max;
     if (n_red > 16384 && lin == SFMBA_SOLVER_DENSE)
         fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)n_red);
@@ -1254,7 +1297,6 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     const int n_cam = (int)h->n_cam;
     const int n_ublk = h->n_ublk, nnzb = h->nnzb;
     const size_t nn = (size_t)h->cd * h->cd;
-    const int64_t n_red = (int64_t)h->cd * n_cam;
     const std::vector<int>& bsr_ptr = h->bsr_ptr_host;
     const std::vector<int>& bsr_col = h->bsr_col_host;
     SetupTrace tr;
@@ -1480,12 +1522,9 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         }
         tr.lap("schur: coarse space");
     }
+    h->dense_n = 0;                 // (sized when first needed: ensure_dense)
     if (want_dense) {
-        h->dense_n = dense_padded((int)n_red);
-        h->denseA.alloc((size_t)h->dense_n * h->dense_n);
-        h->denseLinv.alloc((size_t)h->dense_n * 32);
-        h->denseWork.alloc((size_t)h->dense_n * 2);
-        h->dense_fail.alloc(1);
+        ensure_dense(h);
         h->use_dense = true;
     }
 }
@@ -1852,7 +1891,7 @@ void sfmba_default_options(sfmba_options* o) {
     if (!o) return;
     memset(o, 0, sizeof *o);
     o->ftol = 1e-4; o->xtol = 1e-12; o->gtol = 1e-8; o->max_nfev = 0;
-    o->max_iterations = 200; o->initial_lambda = 1e-4; o->pcg_rtol = 0.0; o->pcg_max_iter = 1000;
+    o->max_iterations = 200; o->initial_lambda = 0.0; o->pcg_rtol = 0.0; o->pcg_max_iter = 1000;
     o->linear_solver = SFMBA_SOLVER_AUTO; o->dense_max_dim = 1536; o->verbose = 0; o->profile = 0; o->device = -1;
     o->rank = 0; o->nranks = 1;
     o->pcg_mode = 0; o->pcg_blocks = 0;
@@ -2214,6 +2253,7 @@ int sfmba_solve_step(sfmba_handle* h, double* step_cam, double* step_pt, int32_t
         need_linearized(h, "sfmba_solve_step");
         fetch_new2old(h);
         int it = phase_linear_solve(h, h->lin_lambda);
+        if (it < 0) fail(SFMBA_ERR_INVALID_ARGUMENT, "sfmba_solve_step: the reduced matrix is not positive definite at this damping");
         if (pcg_iters) *pcg_iters = it;
         DBuf<double> dp;
         dp.alloc((size_t)std::max(h->n_pts, 1) * 3);

@@ -256,5 +256,9 @@ void launch_reprojection_errors(const double* P, int n, const double* X, const d
 int dense_padded(int n_real);
 void launch_dense_cholesky_solve(double* A, int n, int n_real, double* Linv_all, double* work, int* fail,
                                  const double* b, double* x, hipStream_t st);
+// sfmba_chol.hip: the same solve in one launch (block rows exchange tiles by data flow)
+size_t chol_flow_words(int n);
+hipError_t launch_chol_flow(const double* A, int n, int n_real, const double* b, double* x, double* buf, int* fail,
+                            double* fail_slot, double* fail_host, hipStream_t st, long long* trace = nullptr);
 
 }  // namespace sfmba

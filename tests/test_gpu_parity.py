@@ -271,13 +271,50 @@ def test_unobserved_camera_and_point_stay_where_they_are():
 
 
 def test_dense_cholesky_is_the_fallback_when_pcg_runs_out_of_iterations():
-    g = load_golden("shuffled_9_200_700")
-    with make_engine(g, pcg_max_iter=1, pcg_rtol=1e-8) as eng:      # AUTO: PCG first
+    # (more than the 53 cameras up to which the library factors the camera system to begin with)
+    p = syn.make_problem(60, 500, 2000, seed=4, window=6)
+    ref = o.solve_reference(p)
+    with make_engine(p, pcg_max_iter=1, pcg_rtol=1e-8) as eng:      # AUTO: PCG first
         st = eng.solve()
     assert st.linear_solver == 1 and st.n_dense > 0                 # steps re-solved by Cholesky
-    assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)
-    with make_engine(g) as eng:                                      # healthy PCG: no factorisation
+    assert st.final_cost <= ref["cost"] * (1 + 1e-6)
+    with make_engine(p) as eng:                                      # healthy PCG: no factorisation
         assert eng.solve().n_dense == 0
+
+
+def test_dense_fallback_on_a_handle_that_held_a_smaller_problem():
+    """The factorisation's buffers follow the problem: a handle whose fallback fired with 60
+    cameras loads 70 cameras and the fallback fires again (the reference's driver calls bundle
+    adjustment with one more view every time, main.py:103-116)."""
+    small = syn.make_problem(60, 500, 2000, seed=4, window=6)
+    large = syn.make_problem(70, 600, 2400, seed=5, window=6)
+    with make_engine(large, pcg_max_iter=1, pcg_rtol=1e-8) as eng:
+        alone = eng.solve()
+    with make_engine(small, pcg_max_iter=1, pcg_rtol=1e-8) as eng:
+        assert eng.solve().n_dense > 0
+        eng.set_problem(large["camera_params"], large["points_3d"], large["camera_indices"],
+                        large["point_indices"], large["points_2d"], large["K"])
+        st = eng.solve()
+    assert st.n_dense > 0 and st.final_cost == alone.final_cost and st.iterations == alone.iterations
+    assert st.final_cost <= o.solve_reference(large)["cost"] * (1 + 1e-6)
+
+
+def test_small_camera_systems_are_factored_and_start_undamped():
+    """Left to choose, up to 53 cameras are solved by the single-launch Cholesky with Gauss-Newton
+    steps from the start; the multi-launch factorisation gives the same steps."""
+    g = load_golden("shuffled_9_200_700")
+    with make_engine(g) as eng:
+        st = eng.solve()
+    assert st.linear_solver == 2 and st.pcg_iterations == 0 and st.n_dense == st.iterations
+    assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)
+    import os
+    os.environ["SFMBA_DENSE_FLOW"] = "0"
+    try:
+        with make_engine(g) as eng:
+            chain = eng.solve()
+    finally:
+        del os.environ["SFMBA_DENSE_FLOW"]
+    assert chain.iterations == st.iterations and abs(chain.final_cost - st.final_cost) <= 1e-9 * st.final_cost
 
 
 def test_inputs_are_not_modified_and_solve_is_deterministic():
