@@ -23,6 +23,8 @@
 // factorisation by then), and workgroups start in index order, so the launch cannot wait on
 // itself; a poll that exceeds its time limit raises the abort word, every poller checks it, and
 // the caller takes the multi-launch path.
+#include <algorithm>
+
 #include "sfmba_internal.h"
 
 namespace sfmba {
@@ -325,6 +327,33 @@ __global__ __launch_bounds__(256) void k_chol_flow(CholArgs a) {
     stamp(6);
 }
 
+// Everything the factorisation launch needs, in one pass: the lower triangle of the dense matrix
+// gathered from the block-CSR matrix (blocks of a row are sorted by column: binary search, absent
+// blocks are zero), the exchange buffer armed with the sentinel, the failure words cleared.
+__global__ __launch_bounds__(256) void k_chol_prepare(Dev d, int nd, double* __restrict__ A, int n, int n_real,
+                                                      unsigned long long* __restrict__ buf, size_t words,
+                                                      int* __restrict__ fail, double* __restrict__ fail_slot) {
+    const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (t0 == 0) { *fail = 0; if (fail_slot) *fail_slot = 0.0; }
+    for (size_t t = t0; t < words; t += stride) buf[t] = kSentinel;
+    for (size_t t = t0; t < (size_t)n * n; t += stride) {
+        const int row = (int)(t / n), col = (int)(t - (size_t)row * n);
+        if (col > row) continue;
+        double v = 0.0;
+        if (row < n_real) {
+            const int r = row / nd, c = col / nd;
+            int lo = d.bsr_ptr[r], hi = d.bsr_ptr[r + 1];
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (d.bsr_col[mid] < c) lo = mid + 1; else hi = mid;
+            }
+            if (lo < d.bsr_ptr[r + 1] && d.bsr_col[lo] == c)
+                v = d.Sfull[(size_t)lo * nd * nd + (row - nd * r) * nd + (col - nd * c)];
+        }
+        A[t] = v;
+    }
+}
+
 }  // namespace
 
 size_t chol_flow_words(int n) {
@@ -332,21 +361,23 @@ size_t chol_flow_words(int n) {
     return tile_at(nb, 0) + 2 * (size_t)n + 8;
 }
 
-// Solves A x = b for the n_real x n_real leading part of the dense row-major matrix A (leading
-// dimension n = n_real rounded up to a multiple of 32; the lower triangle is read).  buf holds
-// chol_flow_words(n) doubles.  *fail (and fail_slot / fail_host when given): 0 fine, 1 a pivot was
-// not positive, 2 the launch was given up.
-hipError_t launch_chol_flow(const double* A, int n, int n_real, const double* b, double* x, double* buf, int* fail,
+// Solves S x = b for the reduced matrix in d.Sfull (block-CSR) through the dense work array A
+// (leading dimension n = n_real rounded up to a multiple of 32).  buf holds chol_flow_words(n)
+// doubles.  *fail, and fail_slot / fail_host when given (a scalar slot on the device and the same
+// slot in pinned host memory): 0 fine, 1 a pivot was not positive, 2 the launch was given up.
+// Two launches; nothing is waited for.
+hipError_t launch_chol_flow(const Dev& d, double* A, int n, int n_real, const double* b, double* x, double* buf, int* fail,
                             double* fail_slot, double* fail_host, hipStream_t st, long long* trace) {
     CholArgs a{};
     a.trace = trace;
     a.A = A; a.b = b; a.x = x; a.buf = buf; a.fail = fail; a.fail_slot = fail_slot; a.fail_host = fail_host;
     a.n = n; a.n_real = n_real; a.nb = n / NB;
     a.timeout_ticks = 20000000LL;       // 0.2 s of the 100 MHz wall clock
-    hipError_t e = hipMemsetAsync(buf, 0xFF, chol_flow_words(n) * sizeof(double), st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(fail, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
+    if (fail_host) *fail_host = 0.0;    // (the kernel writes it only on failure, the host reads it after its wait)
+    const size_t words = chol_flow_words(n);
+    const int blocks = (int)std::min<size_t>(1024, ((size_t)n * n + 255) / 256);
+    hipLaunchKernelGGL(k_chol_prepare, dim3(blocks), dim3(256), 0, st, d, cam_dim(d), A, n, n_real,
+                       reinterpret_cast<unsigned long long*>(buf), words, fail, fail_slot);
     hipLaunchKernelGGL(k_chol_flow, dim3(a.nb), dim3(256), 0, st, a);
     return hipGetLastError();
 }

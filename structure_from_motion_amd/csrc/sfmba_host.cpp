@@ -620,19 +620,17 @@ void ensure_dense(H* h) {
 bool phase_dense(H* h) {
     Scope t(h, F_DENSE);
     const int n = h->dense_n, n_real = h->cd * (int)h->n_cam;
-    h->denseA.zero(h->stream);
-    launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
     int failed = 0;
     if (h->dense_flow) {
-        HIP_TRY(launch_chol_flow(h->denseA.p, n, n_real, h->rhs.p, h->px.p, h->denseFlow.p, h->dense_fail.p, nullptr, nullptr, h->stream));
+        HIP_TRY(launch_chol_flow(h->dev, h->denseA.p, n, n_real, h->rhs.p, h->px.p, h->denseFlow.p, h->dense_fail.p, nullptr, nullptr, h->stream));
         HIP_TRY(hipMemcpyAsync(&failed, h->dense_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (failed != 2) return failed == 0;
         // given up (time limit: the workgroups were not resident together): the chain of launches
         h->dense_flow = false;
-        h->denseA.zero(h->stream);
-        launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
     }
+    h->denseA.zero(h->stream);
+    launch_bsr_to_dense(h->dev, h->denseA.p, n, h->stream);
     h->dense_fail.zero(h->stream);
     launch_dense_cholesky_solve(h->denseA.p, n, n_real, h->denseLinv.p, h->denseWork.p, h->dense_fail.p, h->rhs.p, h->px.p, h->stream);
     HIP_TRY(hipMemcpyAsync(&failed, h->dense_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -673,6 +671,15 @@ constexpr double kPcgRefused = 1024.0;
 // synchronisation and, between ranks, a collective per LM iteration.  Returns false when the solve
 // has to take the synchronous route (other solver, launch refused earlier).
 bool launch_linear_solve_async(H* h) {
+    if (h->explicit_schur && h->use_dense && h->dense_flow && h->dense_auto) {
+        // single-launch factorisation: its failure word (1: not positive definite, 2: given up)
+        // travels in the same slot
+        Scope t(h, F_DENSE);
+        const int n = h->dense_n, n_real = h->cd * (int)h->n_cam;
+        HIP_TRY(launch_chol_flow(h->dev, h->denseA.p, n, n_real, h->rhs.p, h->px.p, h->denseFlow.p, h->dense_fail.p,
+                                 h->scalars.p + SLOT_PCGFLAG, h->has_comm() ? nullptr : h->scalars_host + SLOT_PCGFLAG, h->stream));
+        return true;
+    }
     if (!(h->explicit_schur && h->fused_pcg && !h->use_dense)) return false;
     if (h->fused_refused && !h->has_comm()) { h->fused_pcg = false; return false; }
     const double tol = pcg_rtol_of(h);
@@ -802,6 +809,7 @@ void do_solve(H* h, sfmba_stats* out) {
     bool lin_pending = false;
     for (int it = 0; it < max_it && status < 0; ++it) {
         phase_damp(h, lambda);
+        const bool pending_dense = h->use_dense && h->dense_flow && h->dense_auto;
         const bool pending = launch_linear_solve_async(h);
         if (!pending) {
             const int its = phase_linear_solve(h, lambda);
@@ -821,7 +829,30 @@ void do_solve(H* h, sfmba_stats* out) {
         } else {
             read_scalars(h, sc);
         }
-        if (pending) {
+        if (pending && pending_dense) {
+            // the factorisation's failure word, summed over the ranks (which all factor the same matrix)
+            const double flag = sc[SLOT_PCGFLAG];
+            if (flag != 0.0) {
+                const double all_ranks = h->has_comm() ? (double)o.nranks : 1.0;
+                if (flag != all_ranks) {
+                    // given up somewhere (time limit): every rank takes the chain of launches from now on
+                    h->dense_flow = false;
+                    const int its = phase_linear_solve(h, lambda, false);
+                    if (its >= 0) {
+                        HIP_TRY(hipMemsetAsync(h->scalars.p + SLOT_PCGFLAG, 0, sizeof(double), h->stream));
+                        phase_trial(h, nullptr);
+                        read_scalars(h, sc);
+                    }
+                    if (its < 0) { lambda = std::max(16.0 * lambda, 1e-8); if (lambda > 1e32) status = SFMBA_STATUS_XTOL; continue; }
+                } else {
+                    // not positive definite to working precision at this damping
+                    h->dense_fallbacks++;
+                    lambda = std::max(16.0 * lambda, 1e-8);
+                    if (lambda > 1e32) status = SFMBA_STATUS_XTOL;
+                    continue;
+                }
+            }
+        } else if (pending) {
             // identical on every rank: the flag is the ranks' sum, the state that of the same
             // replicated solve
             const PcgState ps = h->pcg_host[0];

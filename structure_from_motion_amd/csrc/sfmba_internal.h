@@ -258,7 +258,7 @@ void launch_dense_cholesky_solve(double* A, int n, int n_real, double* Linv_all,
                                  const double* b, double* x, hipStream_t st);
 // sfmba_chol.hip: the same solve in one launch (block rows exchange tiles by data flow)
 size_t chol_flow_words(int n);
-hipError_t launch_chol_flow(const double* A, int n, int n_real, const double* b, double* x, double* buf, int* fail,
+hipError_t launch_chol_flow(const Dev& d, double* A, int n, int n_real, const double* b, double* x, double* buf, int* fail,
                             double* fail_slot, double* fail_host, hipStream_t st, long long* trace = nullptr);
 
 }  // namespace sfmba
