@@ -78,6 +78,53 @@ def cpu_baseline(scale, seed, camera_model="pinhole"):
     }
 
 
+def through_class(shape, seed):
+    """The hot path the way the reference's driver runs it (main.py:103-124): after every
+    integrated view a new BundleAdjustment(wpSet, K, dist, views) and optimize() on everything seen
+    so far, then the write-back of poses and points.  Timed whole - packing the pandas table,
+    loading the problem, the solve, reading back, write-back - on a problem of the given shape that
+    grows view by view (two observations per point); one untimed loop first, so that handles and
+    allocations are warm as they are from the second image on."""
+    import contextlib
+    import io
+    import tempfile
+    import pandas as pd
+    from structure_from_motion_amd import bundle_adjustment as ba
+    from structure_from_motion_amd import synthetic as syn
+    p = syn.make_shape(shape, seed=seed)
+    dist = np.zeros((1, 5))
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())            # optimize() writes optimize_data.npz
+    calls = []
+    try:
+        for timed in (False, True):
+            views, steps, K = syn.growing_tables(p)
+            wp = syn.SyntheticWorldPoints(np.empty((0, 3)), pd.DataFrame({"ViewId": [], "FeatureIndex": []}))
+            for k, (rows, pts) in enumerate(steps, start=1):
+                wp.correspondences = pd.concat((wp.correspondences, rows), ignore_index=True)
+                wp.world_points = np.vstack((wp.world_points, pts))
+                if not len(wp.correspondences):
+                    continue
+                with contextlib.redirect_stdout(io.StringIO()):
+                    t0 = time.perf_counter()
+                    b = ba.BundleAdjustment(wp, K, dist, views[:k + 1])
+                    b.optimize()
+                    b.write_back()
+                    total = time.perf_counter() - t0
+                if timed:
+                    calls.append(dict(views=k + 1, points=b.n_points, seconds=total, lm_iterations=b.result["iterations"],
+                                      stages={k2: round(v, 6) for k2, v in b.timings.items()}))
+    finally:
+        os.chdir(cwd)
+        ba.release_engines()
+    last = calls[-1]
+    return {"optimize_class_seconds": last["seconds"], "last_call": last,
+            "loop_seconds": sum(c["seconds"] for c in calls), "calls": len(calls),
+            "seconds_per_call": [round(c["seconds"], 6) for c in calls],
+            "what": "BundleAdjustment(...).optimize() + write_back() per integrated view, whole call on the host clock "
+                    "(pandas packing, optimize_data.npz, set-up, solve, read-back, write-back)"}
+
+
 def spawn_ranks(n):
     """Parent of an N-rank run: start the ranks as fresh child processes before anything here has
     touched a GPU (counting devices does not), pass rank 0's line through, fail if any rank fails."""
@@ -118,6 +165,9 @@ def main():
     ap.add_argument("--pcg-mode", type=int, default=0, help="0 auto, 1 two launches per iteration, 2 single launch")
     ap.add_argument("--pcg-coarse", type=int, default=0,
                     help="two-level PCG preconditioner: 0 default policy, -1 off, k clusters of k cameras")
+    ap.add_argument("--through-class", action="store_true",
+                    help="also time BundleAdjustment.optimize() whole, view by view, on a growing problem of --shape "
+                         "(fountain or temple: two observations per point), reported as optimize_class_seconds")
     ap.add_argument("--camera-model", default="pinhole", choices=("pinhole", "bal"),
                     help="pinhole: the 12-number camera of bundle_adjustment.py (the headline workload); "
                          "bal: the 9-number camera of ba_test.py on the same scene")
@@ -305,6 +355,13 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
 
+    klass = None
+    if rank == 0 and args.through_class:
+        if world > 1 or bal or args.shape not in ("fountain", "temple") or args.scale != 1.0:
+            sys.stderr.write("bench.py: --through-class needs one GPU, the pinhole camera and --shape fountain or temple\n")
+            sys.exit(2)
+        klass = through_class(args.shape, args.seed)
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_scale, args.seed, args.camera_model)
@@ -340,8 +397,15 @@ def main():
             "setup_seconds_device_inputs": setup_dev_s,
             "optimize_seconds_end_to_end": setup_warm_s + elapsed / args.steps,
             "pcg_single_fallbacks_per_solve": sum(s.pcg_single_fallbacks for s in stats) / args.steps,
-            "roofline": roof, "kernels": families, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": families,
+            "kernels_note": "per-family totals of one extra solve with HIP events around every launch: launches are "
+                            "serialised there (the coarse set-up of the second stream no longer overlaps), so their sum "
+                            "exceeds ms_per_step",
+            "cpu_baseline": cpu,
         }
+        if klass is not None:
+            out["optimize_class_seconds"] = klass["optimize_class_seconds"]
+            out["optimize_class"] = klass
         if multi is not None:
             out["multi_gpu"] = multi
         print(json.dumps(out), flush=True)

@@ -8,7 +8,12 @@ cv2.Rodrigues / cv2.projectPoints (/root/reference/bundle_adjustment.py:24,28) a
 not installed here, the reference has no tests or golden vectors for this path, and its
 module cannot be imported without cv2.  The projection below is therefore a restatement of
 OpenCV 4.5.2's documented algorithm (opencv-python==4.5.2.54, requirements.txt:10), not a
-run of it.  The optimiser boundary is NOT restated: `solve_reference` drives the real
+run of it.  One half of it IS pinned by the reference's own code: the vector -> matrix map below
+equals the `rotated` outputs of the reference's ba_test.rotate (ba_test.py:62-75, the same
+Rodrigues formula) stored in tests/golden/bal_ref_*.npz to 1e-15, zero vector included
+(tests/test_oracle.py::test_vector_to_matrix_rotation_pinned_by_the_reference_script).  What stays
+unpinned after that is cv2's matrix -> vector branch logic (polar factor, small-angle snap, the
+half-turn branch) and the two-line pinhole map.  The optimiser boundary is NOT restated: `solve_reference` drives the real
 scipy.optimize.least_squares with the reference's own keyword arguments
 (/root/reference/bundle_adjustment.py:141-143); the installed SciPy is 1.15.3, the
 reference pins scipy~=1.5.4 (requirements.txt:20).

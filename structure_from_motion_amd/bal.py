@@ -16,12 +16,12 @@ import bz2
 import numpy as np
 from scipy.sparse import csr_matrix
 
-from .bundle_adjustment import _digest
+from .bundle_adjustment import _ObservationCache, _engine_lock
 from .engine import Engine, TERMINATION_MESSAGES
 
 __all__ = ["read_bal_data", "write_bal_data", "rotate", "project", "fun", "bundle_adjustment_sparsity", "solve"]
 
-_fun_cache = {"key": None, "engine": None}
+_fun_cache = _ObservationCache()
 
 
 def _numbers(text):
@@ -115,19 +115,18 @@ def project(points, camera_params):
 
 
 def _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d):
-    ci = np.asarray(camera_indices)
-    pi = np.asarray(point_indices)
-    uv = np.asarray(points_2d)
-    key = (n_cameras, n_points, _digest(ci), _digest(pi), _digest(uv))     # by content, as in bundle_adjustment.fun
-    if _fun_cache["key"] != key:
-        if _fun_cache["engine"] is not None:
-            _fun_cache["engine"].close()
-        _fun_cache.update(key=None, engine=None)
+    def make(ci, pi, uv):
         eng = Engine(camera_model="bal", schur_mode=1)      # residuals only
-        eng.set_problem(np.tile(np.r_[np.zeros(5), -1.0, 1.0, 0.0, 0.0], (n_cameras, 1)),
-                        np.zeros((n_points, 3)), ci, pi, uv, None)
-        _fun_cache.update(key=key, engine=eng)
-    return _fun_cache["engine"]
+        try:
+            eng.set_problem(np.tile(np.r_[np.zeros(5), -1.0, 1.0, 0.0, 0.0], (n_cameras, 1)),
+                            np.zeros((n_points, 3)), ci, pi, uv, None)
+        except Exception:
+            eng.close()
+            raise
+        return eng
+
+    # (kept between calls by content, as in bundle_adjustment.fun)
+    return _fun_cache.get((n_cameras, n_points), (camera_indices, point_indices, points_2d), make)
 
 
 def fun(params, n_cameras, n_points, camera_indices, point_indices, points_2d):
@@ -136,9 +135,10 @@ def fun(params, n_cameras, n_points, camera_indices, point_indices, points_2d):
     params = np.ascontiguousarray(params, dtype=np.float64)
     camera_params = params[:n_cameras * 9].reshape((n_cameras, 9))
     points_3d = params[n_cameras * 9:].reshape((n_points, 3))
-    eng = _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d)
-    eng.set_params(camera_params, points_3d)
-    return eng.residuals()
+    with _engine_lock:
+        eng = _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d)
+        eng.set_params(camera_params, points_3d)
+        return eng.residuals()
 
 
 def bundle_adjustment_sparsity(n_cameras, n_points, camera_indices, point_indices):

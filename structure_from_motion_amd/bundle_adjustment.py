@@ -12,10 +12,15 @@ There is no CPU fallback: without the shared library or without a GPU these func
 from __future__ import annotations
 
 import atexit
-import hashlib
+import gc
+from concurrent.futures import ThreadPoolExecutor
 import logging
 from itertools import chain
+import operator
+import os
+import threading
 import time
+import weakref
 
 import numpy as np
 import pandas as pd
@@ -25,7 +30,9 @@ from .engine import Engine, TERMINATION_MESSAGES
 
 __all__ = ["project", "fun", "bundle_adjustment_sparsity", "BundleAdjustment", "solve_arrays", "solve_npz", "release_engines"]
 
-_fun_cache = {"key": None, "engine": None}
+# One lock for the engines kept between calls (below): a handle holds one problem at a time, so
+# set_problem .. solve .. get_params of one call must not interleave with another thread's.
+_engine_lock = threading.RLock()
 # Engines of optimize(), one per set of options, kept between calls: the reference's driver makes a
 # new BundleAdjustment after every image (main.py:115-116), and a handle that already holds device
 # memory loads the next, slightly larger, problem in milliseconds instead of allocating afresh.
@@ -44,12 +51,16 @@ def _solve_engine(opts):
 
 def release_engines():
     """Free the device memory held between calls by fun() and optimize()."""
+    with _engine_lock:
+        _release_engines()
+
+
+def _release_engines():
     for eng in list(_solve_engines.values()):
         eng.close()
     _solve_engines.clear()
-    if _fun_cache["engine"] is not None:
-        _fun_cache["engine"].close()
-    _fun_cache.update(key=None, engine=None)
+    for cache in _observation_caches:       # fun() of this module and of bal.py
+        cache.close()
 
 
 atexit.register(release_engines)
@@ -76,32 +87,71 @@ def project(points, camera_params, K, dist=np.array([])):
         return eng.residuals().reshape(n, 2)
 
 
-def _digest(a):
-    """Content key of an index / observation array: shape, dtype and a hash of the bytes."""
-    a = np.ascontiguousarray(a)
-    return (a.shape, a.dtype.str, hashlib.blake2b(a.view(np.uint8).reshape(-1), digest_size=16).digest())
+_compare_pool = None
+_observation_caches = []
+
+
+def _same_arrays(pairs, chunk=1 << 19):
+    """True when every (a, b) of ``pairs`` holds equal contents: a full comparison at memory speed
+    (a few threads on slices of half a million elements; 160 MB of index and observation arrays
+    of 5 M observations take about 10 ms, the arrays of 68 k observations 0.2 ms)."""
+    global _compare_pool
+    jobs = []
+    for a, b in pairs:
+        if a.shape != b.shape or a.dtype != b.dtype:
+            return False
+        a, b = a.reshape(-1), b.reshape(-1)
+        jobs.extend((a[s:s + chunk], b[s:s + chunk]) for s in range(0, a.size, chunk))
+    if len(jobs) <= 2:
+        return all(np.array_equal(x, y) for x, y in jobs)
+    if _compare_pool is None:
+        _compare_pool = ThreadPoolExecutor(4, thread_name_prefix="sfmba-compare")
+    return all(_compare_pool.map(lambda j: np.array_equal(j[0], j[1]), jobs))
+
+
+class _ObservationCache:
+    """The engine of the last ``fun`` call together with PRIVATE COPIES of the index and
+    observation arrays it was loaded with.  ``fun`` is called many times with the same arrays and a
+    new ``params``; every call compares the arguments with the copies (memory speed, see
+    ``_same_arrays``) and reuses the engine when they are equal, so an array edited in place between
+    two calls is seen, as it is by the reference's pure function."""
+
+    def __init__(self):
+        self.engine = self.meta = self.copies = None
+        _observation_caches.append(self)
+
+    def get(self, meta, arrays, make_engine):
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        if self.engine is None or self.meta != meta or not _same_arrays(list(zip(arrays, self.copies))):
+            self.close()
+            eng = make_engine(*arrays)
+            self.engine, self.meta, self.copies = eng, meta, [a.copy() for a in arrays]
+        return self.engine
+
+    def close(self):
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = self.meta = self.copies = None
+
+
+_fun_cache = _ObservationCache()
 
 
 def _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d, K):
-    """Engine holding the observations of ``fun``'s arguments.  ``fun`` is called many times with
-    the same index and observation arrays and a new ``params``; the engine of the last call is
-    kept and reused when the arrays have the same CONTENT (hashing 5 M observations costs a few
-    milliseconds, building the problem tens), so editing an array in place between two calls is
-    seen, as it is by the reference's pure function."""
-    ci = np.asarray(camera_indices)
-    pi = np.asarray(point_indices)
-    uv = np.asarray(points_2d)
+    """Engine holding the observations of ``fun``'s arguments (kept between calls, by content)."""
     Ka = np.asarray(K, dtype=np.float64)
-    key = (n_cameras, n_points, _digest(ci), _digest(pi), _digest(uv), Ka.tobytes())
-    if _fun_cache["key"] != key:
-        if _fun_cache["engine"] is not None:
-            _fun_cache["engine"].close()
-        _fun_cache.update(key=None, engine=None)
+
+    def make(ci, pi, uv):
         eng = Engine(schur_mode=1)      # residuals only: no reduced-matrix structure is built
-        eng.set_problem(np.tile(np.r_[np.eye(3).ravel(), 0, 0, 1.0], (n_cameras, 1)),
-                        np.zeros((n_points, 3)), ci, pi, uv, Ka)
-        _fun_cache.update(key=key, engine=eng)
-    return _fun_cache["engine"]
+        try:
+            eng.set_problem(np.tile(np.r_[np.eye(3).ravel(), 0, 0, 1.0], (n_cameras, 1)),
+                            np.zeros((n_points, 3)), ci, pi, uv, Ka)
+        except Exception:
+            eng.close()
+            raise
+        return eng
+
+    return _fun_cache.get((n_cameras, n_points, Ka.tobytes()), (camera_indices, point_indices, points_2d), make)
 
 
 def fun(params, n_cameras, n_points, camera_indices, point_indices, points_2d, K):
@@ -113,9 +163,10 @@ def fun(params, n_cameras, n_points, camera_indices, point_indices, points_2d, K
     params = np.ascontiguousarray(params, dtype=np.float64)
     camera_params = params[:n_cameras * 12].reshape((n_cameras, 12))
     points_3d = params[n_cameras * 12:].reshape((n_points, 3))
-    eng = _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
-    eng.set_params(camera_params, points_3d)
-    return eng.residuals()
+    with _engine_lock:
+        eng = _engine_for(n_cameras, n_points, camera_indices, point_indices, points_2d, K)
+        eng.set_params(camera_params, points_3d)
+        return eng.residuals()
 
 
 def bundle_adjustment_sparsity(n_cameras, n_points, camera_indices, point_indices):
@@ -137,6 +188,105 @@ def bundle_adjustment_sparsity(n_cameras, n_points, camera_indices, point_indice
     A = csr_matrix((np.ones(cols.size, dtype=int), cols, 15 * np.arange(2 * n_obs + 1)),
                    shape=(2 * n_obs, 12 * n_cameras + 3 * n_points))
     return A.tolil()
+
+
+def _pack_rows(ids, feats, view_idx):
+    """(camera index, image point) of the first two entries of every correspondence row
+    (reference: bundle_adjustment.py:107-115).  An unknown view id raises KeyError, as the
+    reference's dictionary look-up does."""
+    n_rows = len(ids)
+    if all(map((2).__eq__, map(len, ids))) and all(map((2).__eq__, map(len, feats))):
+        # rows are flattened by the interpreter's own iterators, no Python-level loop over them
+        cam = np.fromiter(map(view_idx.__getitem__, chain.from_iterable(ids)), dtype=np.int64, count=2 * n_rows)
+        uv = np.array(list(chain.from_iterable(feats)), dtype=np.float64).reshape(2 * n_rows, -1)
+        return cam, uv
+    # longer rows: the first two entries count
+    view_ids = np.array(ids, dtype=object).reshape(n_rows, -1)[:, :2].ravel() if len(set(map(len, ids))) == 1 else \
+        np.array([r[k] for r in ids for k in (0, 1)], dtype=object)
+    idx = pd.Series(view_ids).map(view_idx)
+    if idx.isna().any():
+        raise KeyError(view_ids[int(np.flatnonzero(idx.isna().to_numpy())[0])])
+    cam = idx.to_numpy(dtype=np.int64)
+    try:
+        xy = np.asarray(feats, dtype=np.float64)                # (rows, >= 2, 2)
+        uv = np.ascontiguousarray(xy[:, :2]).reshape(2 * n_rows, -1)
+    except ValueError:                                          # ragged rows
+        uv = np.array([np.asarray(f[k], dtype=np.float64) for f in feats for k in (0, 1)])
+    return cam, uv
+
+
+class _PackedRows:
+    __slots__ = ("ids", "feats", "views", "cam", "uv")
+
+
+# wpSet -> what view2idx packed for it last time
+_packed = weakref.WeakKeyDictionary()
+
+
+def _remember_rows(wpSet, kept, ids, feats, view_idx, cam, uv):
+    """Keeps the packed arrays and, per row, a shallow COPY of its two lists (the copies of the rows
+    taken over from the last call are taken over as well)."""
+    m = 0 if kept is None else len(kept.ids)
+    rec = _PackedRows()
+    rec.ids = (kept.ids if m else []) + list(map(list, ids[m:]))
+    rec.feats = (kept.feats if m else []) + list(map(list, feats[m:]))
+    rec.views, rec.cam, rec.uv = tuple(view_idx), cam, uv
+    try:
+        _packed[wpSet] = rec
+    except TypeError:               # an object that cannot be referenced weakly: nothing is kept
+        pass
+
+
+def _first_difference(rows, copies):
+    """Index of the first row whose list no longer equals its copy (entries compared by identity
+    first, as list comparison does; two different keypoint arrays count as different)."""
+    for i, (a, b) in enumerate(zip(rows, copies)):
+        try:
+            if a != b:
+                return i
+        except ValueError:          # elementwise comparison of two distinct arrays
+            return i
+    return len(copies)
+
+
+def _reusable_rows(wpSet, ids, feats, view_idx):
+    """The record of the last call on ``wpSet`` cut down to the rows that may be taken over, or None.
+
+    Verified, not assumed: the views known then are numbered as they were; every old row's lists
+    equal the shallow copies taken when they were packed - same length, and entry by entry the very
+    same keypoint-array objects and equal view ids (so a row re-bound through ``.at``, an entry
+    replaced inside a list, or a list extended as in WorldPoints.py:54-57 is packed afresh, from the
+    first such row on); and 512 rows spread over the table plus its last 64 pack to the same
+    numbers again.  What this cannot see is a number overwritten INSIDE a keypoint array that was
+    packed before, in a row outside that sample; a caller who does that sets ``SFMBA_REPACK=1``."""
+    try:
+        rec = _packed.get(wpSet)
+    except TypeError:
+        return None
+    if rec is None or os.environ.get("SFMBA_REPACK", "0") != "0":
+        return None
+    m = min(len(rec.ids), len(ids))
+    if m == 0 or rec.uv.ndim != 2 or tuple(view_idx)[:len(rec.views)] != rec.views:
+        return None
+    try:
+        unchanged = ids[:m] == rec.ids[:m] and feats[:m] == rec.feats[:m]      # two list comparisons in C
+    except ValueError:
+        unchanged = False
+    if not unchanged:
+        m = min(_first_difference(ids[:m], rec.ids), _first_difference(feats[:m], rec.feats))
+        if m == 0:
+            return None
+    sample = np.unique(np.concatenate((np.linspace(0, m - 1, min(m, 512)).astype(np.int64), np.arange(max(0, m - 64), m))))
+    try:
+        cam, uv = _pack_rows([ids[i] for i in sample], [feats[i] for i in sample], view_idx)
+    except KeyError:
+        return None
+    pos = np.stack((2 * sample, 2 * sample + 1), axis=1).ravel()
+    if uv.shape[1:] != rec.uv.shape[1:] or not (np.array_equal(cam, rec.cam[pos]) and np.array_equal(uv, rec.uv[pos])):
+        return None
+    out = _PackedRows()
+    out.ids, out.feats, out.views, out.cam, out.uv = rec.ids[:m], rec.feats[:m], rec.views, rec.cam[:2 * m], rec.uv[:2 * m]
+    return out
 
 
 class BundleAdjustment:
@@ -166,11 +316,18 @@ class BundleAdjustment:
         self.reprojection_error = None      # per view, filled by optimize()
         self.reprojection_count = None
         self._poses = self._points_3d = None
+        self._dump_thread = None
+        self.timings = {}                   # seconds per stage of the last optimize() / write_back()
 
-    def view2idx(self):
+    def view2idx(self, _defer_dump=False):
         """
         Takes in a list of views and converts them to indices.  For each 2D point a view index
         is assigned (reference: bundle_adjustment.py:94-126, without the per-row Python loop).
+
+        The reference's driver calls this after every integrated image on a correspondence table
+        that only grew at its tail (main.py:103-116, WorldPoints.py:40-43,62): the packed arrays of
+        the last call on the same ``wpSet`` are reused for the rows that are still the very objects
+        packed then (see ``_reusable_rows``), and only the new rows are packed.
         """
         for view in self.completed_views:
             if view.id not in self.view_idx:
@@ -182,61 +339,94 @@ class BundleAdjustment:
 
         corr = self.correspondences
         n_rows = len(corr)
-        if n_rows:
-            # both columns hold one 2-element list per row; the rows are flattened by the
-            # interpreter's own iterators, there is no Python-level loop over them
-            ids, feats = corr["ViewId"].tolist(), corr["FeatureIndex"].tolist()
-            if all(map((2).__eq__, map(len, ids))) and all(map((2).__eq__, map(len, feats))):
-                # (an unknown id raises KeyError, as the reference's dictionary look-up does)
-                self.camera_indices = np.fromiter(map(self.view_idx.__getitem__, chain.from_iterable(ids)),
-                                                  dtype=np.int64, count=2 * n_rows)
-                self.points_2d = np.array(list(chain.from_iterable(feats)), dtype=np.float64).reshape(2 * n_rows, -1)
-            else:                                                           # longer rows: the first two entries count
-                view_ids = np.array(ids, dtype=object).reshape(n_rows, -1)[:, :2].ravel()
-                idx = pd.Series(view_ids).map(self.view_idx)
-                if idx.isna().any():
-                    raise KeyError(view_ids[int(np.flatnonzero(idx.isna().to_numpy())[0])])
-                self.camera_indices = idx.to_numpy(dtype=np.int64)
-                try:
-                    xy = np.asarray(feats, dtype=np.float64)                # (rows, >= 2, 2)
-                    self.points_2d = np.ascontiguousarray(xy[:, :2]).reshape(2 * n_rows, -1)
-                except ValueError:                                          # ragged rows
-                    self.points_2d = np.array([np.asarray(f[k], dtype=np.float64) for f in feats for k in (0, 1)])
-            self.point_indices = np.repeat(np.asarray(corr.index), 2)
-        else:
-            self.camera_indices = np.array([])
-            self.point_indices = np.array([])
-            self.points_2d = np.array([])
+        # (tens of thousands of row lists are walked and a few thousand created: the cyclic garbage
+        # collector would traverse all of them several times over, 5 ms per call at 34 k rows, and
+        # find nothing)
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._pack_correspondences(corr, n_rows)
+        finally:
+            if gc_was_on:
+                gc.enable()
         self.points_3d = np.array(self.points_3d)
         self.n_points = self.points_3d.shape[0]
         self.n_cameras = self.camera_params.shape[0]
         logging.info(f"Number of views processed: {self.n_cameras}.")
         logging.info(f"Number of 3D points processed: {self.n_points}.")
-        np.savez('optimize_data', camera_params=self.camera_params, points_3d=self.points_3d,
-                 camera_indices=self.camera_indices, point_indices=self.point_indices, points_2d=self.points_2d)
+        # (the file name is resolved now; inside optimize() the file is written beside the solve and
+        # is complete when optimize() returns)
+        dump = dict(camera_params=self.camera_params, points_3d=self.points_3d, camera_indices=self.camera_indices,
+                    point_indices=self.point_indices, points_2d=self.points_2d)
+        path = os.path.abspath('optimize_data')
+        if _defer_dump:
+            self._dump_thread = threading.Thread(target=np.savez, args=(path,), kwargs=dump, name="sfmba-dump")
+            self._dump_thread.start()
+        else:
+            np.savez(path, **dump)
 
+    def _pack_correspondences(self, corr, n_rows):
+        if n_rows:
+            # both columns hold one list per row
+            ids, feats = corr["ViewId"].tolist(), corr["FeatureIndex"].tolist()
+            kept = _reusable_rows(self.wpSet, ids, feats, self.view_idx)
+            m = 0 if kept is None else len(kept.ids)
+            cam_new, uv_new = _pack_rows(ids[m:], feats[m:], self.view_idx) if m < n_rows else (kept.cam[:0], kept.uv[:0])
+            if m and (uv_new.ndim != 2 or uv_new.shape[1:] != kept.uv.shape[1:]):    # another row shape: everything afresh
+                m, (cam_new, uv_new) = 0, _pack_rows(ids, feats, self.view_idx)
+            if m:
+                self.camera_indices = np.concatenate((kept.cam, cam_new))
+                self.points_2d = np.concatenate((kept.uv, uv_new))
+            else:
+                self.camera_indices, self.points_2d = cam_new, uv_new
+            _remember_rows(self.wpSet, kept if m else None, ids, feats, self.view_idx, self.camera_indices, self.points_2d)
+            self.point_indices = np.repeat(np.asarray(corr.index), 2)
+        else:
+            self.camera_indices = np.array([])
+            self.point_indices = np.array([])
+            self.points_2d = np.array([])
     def optimize(self):
         """
         Performs optimization on the reprojection error by updating poses and 3D points.
         :return poses: (N x 12) array, [:9] rotation matrix entries, [9:12] translation
         :return points_3d: optimized 3D points
         """
-        self.view2idx()
+        t0 = time.perf_counter()
+        self.view2idx(_defer_dump=True)
+        self.timings = {"view2idx": time.perf_counter() - t0}
+        try:
+            return self._optimize_packed()
+        finally:
+            t0 = time.perf_counter()
+            self._dump_thread.join()            # optimize_data.npz is complete when this returns
+            self.timings["dump_wait"] = time.perf_counter() - t0
+
+    def _optimize_packed(self):
         print(len(self.camera_params.ravel()), len(self.points_3d.ravel()))
         opts = dict(ftol=self.ftol, xtol=self.xtol, gtol=self.gtol, verbose=int(self.verbose))
         if self.max_nfev:
             opts["max_nfev"] = int(self.max_nfev)
         opts.update(self.engine_options)
-        eng = _solve_engine(opts)
-        eng.set_problem(self.camera_params, self.points_3d, self.camera_indices,
-                        self.point_indices, self.points_2d, self.K)
-        t0 = time.time()
-        stats = eng.solve()
-        t1 = time.time()
-        poses, points_3d = eng.get_params()
-        # per-view mean reprojection error at the optimum (what main.py:123 prints per view
-        # through ImageView.reproject_view), computed where the data already is
-        self.reprojection_error, self.reprojection_count = eng.reprojection_errors()
+        with _engine_lock:
+            eng = _solve_engine(opts)
+            try:
+                ts = time.perf_counter()
+                eng.set_problem(self.camera_params, self.points_3d, self.camera_indices,
+                                self.point_indices, self.points_2d, self.K)
+                t0 = time.time()
+                stats = eng.solve()
+                t1 = time.time()
+                poses, points_3d = eng.get_params()
+                # per-view mean reprojection error at the optimum (what main.py:123 prints per view
+                # through ImageView.reproject_view), computed where the data already is
+                self.reprojection_error, self.reprojection_count = eng.reprojection_errors()
+                self.timings.update(set_problem=t0 - time.time() + time.perf_counter() - ts, solve=t1 - t0,
+                                    read_back=time.time() - t1)
+            except Exception:
+                # a handle that failed half-way is not kept for the next call
+                _solve_engines.pop(tuple(sorted(opts.items())), None)
+                eng.close()
+                raise
         logging.info(f"Optimized {self.n_points} in {t1-t0} seconds.")
         self.result = stats.as_dict()
         self.result["message"] = TERMINATION_MESSAGES[stats.status]
@@ -257,6 +447,7 @@ class BundleAdjustment:
         """
         if getattr(self, "_poses", None) is None:
             raise RuntimeError("write_back: call optimize() first")
+        t_start = time.perf_counter()
         poses, points_3d = self._poses, self._points_3d
         self.wpSet.world_points = points_3d
         ci2 = np.asarray(self.camera_indices).reshape(-1, 2)
@@ -272,6 +463,7 @@ class BundleAdjustment:
             view.world_points = np.hstack((uv, points_3d[rows])) if rows.size else np.empty((0, 5))
             if print_error:
                 print(f"Reprojection error for image{getattr(view, 'name', view.id)} is {self.reprojection_error[k]}")
+        self.timings["write_back"] = time.perf_counter() - t_start
         return self.reprojection_error
 
 

@@ -30,6 +30,7 @@ SHAPES = {
     "ladybug": (49, 7776, 31843),
     "venice": (1778, 993923, 5001946),
     "final": (13682, 4456117, 28987644),
+    "temple": (47, 1840, 3680),         # the ring of 47 views, two-view tracks (40 per pair of neighbours)
 }
 
 
@@ -137,6 +138,8 @@ def make_problem(n_cameras, n_points, n_obs, seed=0, window=12, K=None, noise_px
 def make_shape(name, seed=0, scale=1.0, **kw):
     """One of the named benchmark shapes, optionally scaled down by ``scale`` (<= 1)."""
     nc, npts, no = SHAPES[name]
+    if name == "temple":
+        kw.setdefault("window", 2)          # tracks join neighbouring views only
     if scale != 1.0:
         nc = max(4, int(round(nc * scale)))
         npts = max(8, int(round(npts * scale)))
@@ -228,3 +231,43 @@ def make_bal_problem(n_cameras, n_points, n_obs, seed=0, window=12, noise_px=0.5
             "points_2d": uv, "n_cameras": n_cameras, "n_points": n_points, "n_obs": n_obs,
             "true_camera_params": np.hstack([_rotation_vectors(R), t, f[:, None], k1[:, None], k2[:, None]]),
             "true_points_3d": X}
+
+
+class SyntheticView:
+    """The attributes of the reference's ImageView that bundle adjustment reads and its driver
+    writes back (view.py:33,39,46; main.py:117-121)."""
+
+    def __init__(self, vid, rotation, translation):
+        self.id, self.name = vid, vid
+        self.rotation = rotation
+        self.translation = np.asarray(translation, dtype=np.float64).reshape(3, 1)
+        self.world_points = None
+
+
+class SyntheticWorldPoints:
+    """world_points + correspondences of the reference's WorldPointSet (WorldPoints.py:12-15)."""
+
+    def __init__(self, world_points, correspondences):
+        self.world_points, self.correspondences = world_points, correspondences
+
+
+def growing_tables(prob):
+    """A two-observations-per-point problem as the reference's driver would meet it: the views in
+    order and, per integrated view k >= 1, the correspondence rows (one per point, ``ViewId`` /
+    ``FeatureIndex`` lists as WorldPoints.py:40-43 builds them) and initial points that become known
+    with it, i.e. whose later view is k.  Returns (views, [(rows DataFrame, points)], K)."""
+    import pandas as pd
+    ci = np.asarray(prob["camera_indices"]).reshape(-1, 2)
+    if not np.array_equal(np.asarray(prob["point_indices"]).reshape(-1, 2), np.repeat(np.arange(len(ci)), 2).reshape(-1, 2)):
+        raise ValueError("growing_tables needs two observations per point, point-sorted")
+    uv = np.asarray(prob["points_2d"], dtype=np.float64).reshape(-1, 2, 2)
+    cp = prob["camera_params"]
+    views = [SyntheticView(f"view{j:04d}", cp[j, :9].reshape(3, 3).copy(), cp[j, 9:].copy()) for j in range(len(cp))]
+    later = ci.max(axis=1)
+    steps = []
+    for k in range(1, len(cp)):
+        rows = np.flatnonzero(later == k)
+        frame = pd.DataFrame({"ViewId": [[views[a].id, views[b].id] for a, b in ci[rows]],
+                              "FeatureIndex": [[uv[i, 0], uv[i, 1]] for i in rows]})
+        steps.append((frame, prob["points_3d"][rows]))
+    return views, steps, prob["K"]

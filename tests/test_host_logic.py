@@ -109,3 +109,75 @@ def test_npz_round_trip(tmp_path):
     for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d"):
         assert np.array_equal(p[k], q[k])
     assert abs(o.cost(p) - o.cost(q)) == 0
+
+
+def _growing_table(n_views=6, per_pair=50, seed=3):
+    rng = np.random.default_rng(seed)
+    views = [FakeView(f"id{j}", np.eye(3) + 0.01 * rng.normal(size=(3, 3)), rng.normal(size=3)) for j in range(n_views)]
+    rows = [pd.DataFrame({"ViewId": [[f"id{k - 1}", f"id{k}"] for _ in range(per_pair)],
+                          "FeatureIndex": [[rng.uniform(0, 640, 2), rng.uniform(0, 480, 2)] for _ in range(per_pair)]})
+            for k in range(1, n_views)]
+    return views, rows, rng
+
+
+def _check_against_reference(b, views, corr):
+    cp, cidx, pidx, p2d, vidx = _reference_view2idx(views, corr)
+    assert np.array_equal(b.camera_params, cp) and np.array_equal(b.camera_indices, cidx)
+    assert np.array_equal(b.point_indices, pidx) and np.array_equal(b.points_2d, p2d) and b.view_idx == vidx
+
+
+def test_view2idx_reuses_what_it_packed_for_a_growing_table(tmp_path, monkeypatch):
+    """The reference's driver packs the whole table again after every image (main.py:103-116); here
+    the rows already packed for the same wpSet are taken over once verified, only new rows are
+    packed - and the arrays equal the reference's loops every time."""
+    monkeypatch.chdir(tmp_path)
+    views, rows, rng = _growing_table()
+    K, dist = np.eye(3), np.zeros((1, 5))
+    wp = FakeWorldPoints(np.empty((0, 3)), pd.DataFrame({"ViewId": [], "FeatureIndex": []}))
+    packed = []
+    real = ba._pack_rows
+    monkeypatch.setattr(ba, "_pack_rows", lambda ids, feats, vi: (packed.append(len(ids)), real(ids, feats, vi))[1])
+    for k in range(1, len(views)):
+        wp.correspondences = pd.concat((wp.correspondences, rows[k - 1]), ignore_index=True)
+        wp.world_points = np.vstack((wp.world_points, rng.normal(size=(len(rows[k - 1]), 3))))
+        packed.clear()
+        b = ba.BundleAdjustment(wp, K, dist, views[:k + 1])
+        b.view2idx()
+        _check_against_reference(b, views[:k + 1], wp.correspondences)
+        # first call: all 50 rows; later: the sample that verifies the old rows (all of them in a
+        # table this small), then the 50 new rows on their own
+        assert packed == ([50] if k == 1 else [50 * (k - 1), 50])
+    # a row re-bound through .at, as WorldPoints.py:54-57 does for redundant views ...
+    new_uv = [np.array([1.5, 2.5]), np.array([3.5, 4.5])]
+    wp.correspondences.at[70, "FeatureIndex"] = new_uv
+    b = ba.BundleAdjustment(wp, K, dist, views); b.view2idx()
+    _check_against_reference(b, views, wp.correspondences)
+    assert np.array_equal(b.points_2d[140], new_uv[0])
+    # ... an entry replaced inside a row's own list, a view id changed in place ...
+    wp.correspondences.at[20, "FeatureIndex"][1] = np.array([9.0, 8.0])
+    wp.correspondences.at[30, "ViewId"][0] = "id5"
+    b = ba.BundleAdjustment(wp, K, dist, views); b.view2idx()
+    _check_against_reference(b, views, wp.correspondences)
+    assert np.array_equal(b.points_2d[41], [9.0, 8.0]) and b.camera_indices[60] == 5
+    # ... a list extended past its second entry (nothing packed changes), rows dropped at the tail,
+    # and the views handed over in another order (every camera index changes)
+    wp.correspondences.at[10, "FeatureIndex"] += [np.array([0.0, 0.0])]
+    wp.correspondences.at[10, "ViewId"] += ["id0"]
+    b = ba.BundleAdjustment(wp, K, dist, views); b.view2idx()
+    _check_against_reference(b, views, wp.correspondences)
+    wp.correspondences = wp.correspondences.iloc[:120].reset_index(drop=True)
+    wp.world_points = wp.world_points[:120]
+    b = ba.BundleAdjustment(wp, K, dist, views); b.view2idx()
+    _check_against_reference(b, views, wp.correspondences)
+    b = ba.BundleAdjustment(wp, K, dist, views[::-1]); b.view2idx()
+    _check_against_reference(b, views[::-1], wp.correspondences)
+
+
+def test_fun_cache_compares_contents_at_memory_speed():
+    rng = np.random.default_rng(0)
+    a = [rng.integers(0, 9, 700_000), rng.random((700_000, 2))]
+    b = [x.copy() for x in a]
+    assert ba._same_arrays(list(zip(a, b)))
+    b[1][-1, 1] += 1e-9                                     # one number in the last chunk
+    assert not ba._same_arrays(list(zip(a, b)))
+    assert not ba._same_arrays([(a[0], a[0].astype(np.int32))]) and not ba._same_arrays([(a[0], a[0][:-1])])

@@ -96,3 +96,30 @@ def test_reference_solve_reproduces_golden():
     assert r["status"] == int(g["ref_status"])
     assert abs(r["cost"] - float(g["ref_cost"])) <= 1e-9 * float(g["ref_cost"])
     assert r["nfev"] == int(g["ref_nfev"])
+
+
+@pytest.mark.parametrize("name", ["bal_ref_6_40", "bal_ref_12_300"])
+def test_vector_to_matrix_rotation_pinned_by_the_reference_script(name):
+    """`rotated` in these fixtures is what the reference's own ba_test.rotate (ba_test.py:62-75)
+    returned for the gathered points and rotation vectors (oracle/gen_golden_bal_ref.py): the
+    same Rodrigues map vector -> rotation that cv2.projectPoints applies inside
+    bundle_adjustment.py:28.  The pinhole oracle's restatement of it, applied as a matrix, must
+    agree to rounding (the script adds three terms per point, a matrix product five per
+    component), including the zero vector of the 12-camera file, where the script's 0/0 is turned
+    into the identity (ba_test.py:68-70)."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    rvec = ref["camera_params"][ref["camera_indices"]][:, :3]
+    X = ref["points_3d"][ref["point_indices"]]
+    R = np.array([o.rodrigues_vector_to_matrix(r) for r in ref["camera_params"][:, :3]])
+    got = np.einsum("nij,nj->ni", R[ref["camera_indices"]], X)
+    scale = np.abs(ref["rotated"]).max()
+    assert np.abs(got - ref["rotated"]).max() <= 1e-15 * max(1.0, scale)
+    if name == "bal_ref_12_300":
+        zero = np.flatnonzero(~rvec.any(axis=1))
+        assert zero.size and np.array_equal(got[zero], X[zero])
+    # every matrix is a rotation, and the matrix -> vector restatement takes it back to the vector
+    # (angle below pi): the two halves of the cv2 round trip are consistent with each other
+    for r, Rm in zip(ref["camera_params"][:, :3], R):
+        assert np.abs(Rm @ Rm.T - np.eye(3)).max() <= 1e-15 * 4
+        assert np.abs(o.rodrigues_matrix_to_vector(Rm) - r).max() <= 1e-12 * max(1.0, np.abs(r).max())
