@@ -15,6 +15,18 @@ from structure_from_motion_amd import synthetic as syn
 from structure_from_motion_amd.engine import Engine
 
 PROBLEMS = {"venice": lambda: syn.make_shape("venice", seed=0),
+            "venice_s1": lambda: syn.make_shape("venice", seed=1), "venice_s2": lambda: syn.make_shape("venice", seed=2),
+            "final0.1": lambda: syn.make_shape("final", seed=0, scale=0.1),
+            "final0.1_s1": lambda: syn.make_shape("final", seed=1, scale=0.1),
+            "venice0.3_s1": lambda: syn.make_shape("venice", seed=1, scale=0.3),
+            "venice0.3_s3": lambda: syn.make_shape("venice", seed=3, scale=0.3), "venice0.3_s4": lambda: syn.make_shape("venice", seed=4, scale=0.3),
+            "venice0.3_hard3": lambda: syn.make_shape("venice", seed=0, scale=0.3, rot_sigma=0.015, trans_sigma=0.03, point_sigma=0.03),
+            "venice0.3_hard10": lambda: syn.make_shape("venice", seed=0, scale=0.3, rot_sigma=0.05, trans_sigma=0.1, point_sigma=0.1),
+            "venice_hard3": lambda: syn.make_shape("venice", seed=0, rot_sigma=0.015, trans_sigma=0.03, point_sigma=0.03),
+            "venice_hard10": lambda: syn.make_shape("venice", seed=0, rot_sigma=0.05, trans_sigma=0.1, point_sigma=0.1),
+            "final0.2_hard3": lambda: syn.make_shape("final", seed=0, scale=0.2, rot_sigma=0.015, trans_sigma=0.03, point_sigma=0.03),
+            "ladybug_hard10": lambda: syn.make_shape("ladybug", seed=0, rot_sigma=0.05, trans_sigma=0.1, point_sigma=0.1),
+            "fountain_hard10": lambda: syn.make_shape("fountain", seed=0, rot_sigma=0.05, trans_sigma=0.1, point_sigma=0.1),
             "venice0.3": lambda: syn.make_shape("venice", seed=0, scale=0.3),
             "venice0.1": lambda: syn.make_shape("venice", seed=0, scale=0.1),
             "temple1": lambda: temple(1), "temple3": lambda: temple(3),

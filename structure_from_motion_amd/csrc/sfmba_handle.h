@@ -191,6 +191,7 @@ struct HandleData {
     const double* fused_einv = nullptr;
     bool fused_coarse_wanted = false; // set up an operator beside the next linearisation
     double solve_rtol = 0.0;          // PCG tolerance of the sfmba_solve in progress (0 outside one)
+    double model_gain_floor = -1.0;   // inside a solve: a PCG iteration that lowers the model by less than this is not worth its time (< 0: rule off)
     DBuf<int> wg_cl;
     hipEvent_t ev_c_assembled = nullptr, ev_c_done = nullptr;
     // dense Cholesky solver

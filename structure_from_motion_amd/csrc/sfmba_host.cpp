@@ -471,14 +471,29 @@ double pcg_rtol_of(const H* h) {
     return h->explicit_schur && h->fused_pcg && !h->use_dense ? 0.03 : 0.1;
 }
 
-PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
+// The stopping rules of a linear solve.  With the tolerance given in the options: the residual rule
+// alone.  Left open, inside a solve: the residual must pass the tolerance of pcg_rtol_of (`loose`)
+// and the iteration goes on while it still lowers the quadratic model by more than a twentieth of
+// what the ftol rule of the outer loop can see (ftol x cost) per iteration, down to `tight`.  Far from
+// the solution that ends a solve early in relative terms, near it the steps become accurate, and
+// the outer loop is not sent into another iteration by the linear solver alone.
+struct PcgStop { double tight, loose, q_abs; };
+PcgStop pcg_stop_of(const H* h) {
     const double tol = pcg_rtol_of(h);
+    if (h->opt.pcg_rtol > 0 || !(h->model_gain_floor >= 0.0)) return {tol, tol, -1.0};
+    return {tol / 30.0, tol, h->model_gain_floor};
+}
+
+PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
+    const PcgStop stop = pcg_stop_of(h);
+    const double tol = stop.tight;
     const int max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
     if (allow_fused && h->explicit_schur && h->fused_pcg) {
         // the whole solve in one launch; a breakdown of the single-reduction
         // recurrence or a barrier timeout falls through to the launch-per-iteration solver
         FusedPcg& f = h->fused;
         f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = max_iter; f.flag_slot = nullptr; f.flag_host = nullptr;
+        f.tol2_loose = stop.loose * stop.loose; f.q_abs = stop.q_abs;
         arm_fused_coarse(h, f);
         hipError_t e = hipErrorNotSupported;
         if (!h->fused_refused) {
@@ -530,7 +545,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
     }
     {
         Scope t(h, F_PCGVEC);
-        launch_pcg_init(h->dev, tol, max_iter, h->stream);
+        launch_pcg_init(h->dev, tol, max_iter, h->stream, stop.loose, stop.q_abs);
         if (two_level) launch_coarse_apply(h->dev, h->coarse, 0, h->stream);
     }
     // Iterations are queued in batches; the state of batch k is copied to pinned host memory
@@ -682,9 +697,11 @@ bool launch_linear_solve_async(H* h) {
     }
     if (!(h->explicit_schur && h->fused_pcg && !h->use_dense)) return false;
     if (h->fused_refused && !h->has_comm()) { h->fused_pcg = false; return false; }
-    const double tol = pcg_rtol_of(h);
+    const PcgStop stop = pcg_stop_of(h);
+    const double tol = stop.tight;
     FusedPcg& f = h->fused;
     f.x = h->px.p; f.out = &h->pcg_host[0]; f.tol2 = tol * tol; f.max_iter = h->opt.pcg_max_iter > 0 ? h->opt.pcg_max_iter : 1000;
+    f.tol2_loose = stop.loose * stop.loose; f.q_abs = stop.q_abs;
     f.flag_slot = h->scalars.p + SLOT_PCGFLAG;
     f.flag_host = h->has_comm() ? nullptr : h->scalars_host + SLOT_PCGFLAG;
     arm_fused_coarse(h, f);
@@ -783,7 +800,24 @@ void do_solve(H* h, sfmba_stats* out) {
     h->fused_coarse_ready = false; h->fused_coarse_wanted = false;
     h->solve_rtol = 0.0;
     h->solve_rtol = pcg_rtol_of(h);
-    struct ClearRtol { H* h; ~ClearRtol() { h->solve_rtol = 0.0; } } clear_rtol{h};
+    struct ClearRtol { H* h; ~ClearRtol() { h->solve_rtol = 0.0; h->model_gain_floor = -1.0; } } clear_rtol{h};
+    // largest cut of the damping after a step: a step the model predicted to 1 % cuts it thirtyfold
+    // (Nielsen's rule with a floor of 1/30 instead of 1/3; tuning: SFMBA_LM_DOWN)
+    double lm_down = 1.0 / 30.0;
+    if (const char* e = getenv("SFMBA_LM_DOWN")) lm_down = atof(e);
+    double gain_fraction = 0.05;             // of ftol x cost, per PCG iteration (tuning: SFMBA_PCG_GAIN, negative = rule off)
+    if (const char* e = getenv("SFMBA_PCG_GAIN")) gain_fraction = atof(e);
+    // tuning hook: SFMBA_RTOL_SCHEDULE="0.03,0.001" gives the PCG tolerance of the first, second, ...
+    // linear solve (the last entry for all later ones) where the options leave it open
+    std::vector<double> rtol_schedule;
+    if (const char* e = getenv("SFMBA_RTOL_SCHEDULE"))
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            const double v = strtod(q, &end);
+            if (end == q) break;
+            if (v > 0) rtol_schedule.push_back(v);
+            q = *end == ',' ? end + 1 : end;
+        }
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
     auto t0 = std::chrono::steady_clock::now();
@@ -808,6 +842,9 @@ void do_solve(H* h, sfmba_stats* out) {
     // iteration), and a step computed from a point that turns out to satisfy gtol is dropped.
     bool lin_pending = false;
     for (int it = 0; it < max_it && status < 0; ++it) {
+        if (!rtol_schedule.empty() && !(o.pcg_rtol > 0))
+            h->solve_rtol = rtol_schedule[std::min<size_t>(st.iterations, rtol_schedule.size() - 1)];
+        h->model_gain_floor = gain_fraction >= 0.0 ? gain_fraction * ftol * cost : -1.0;
         phase_damp(h, lambda);
         const bool pending_dense = h->use_dense && h->dense_flow && h->dense_auto;
         const bool pending = launch_linear_solve_async(h);
@@ -908,7 +945,7 @@ void do_solve(H* h, sfmba_stats* out) {
         if (rho > 1e-3) {
             h->cur ^= 1;
             ++accepted;
-            lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), lambda_floor);
+            lambda = std::max(lambda * std::max(lm_down, 1.0 - std::pow(2.0 * rho - 1.0, 3)), lambda_floor);
             nu = 2.0;
             cost = cost_new;
             // also the gradient norm at the new iterate; damps for the next step, unless this was the last

@@ -40,7 +40,10 @@ enum Slot {
 struct PcgState {
     double rz;        // r'z of the current iterate
     double rz0;       // r'z at iteration 0
-    double tol2;      // stop when rz <= tol2 * rz0
+    double tol2;      // stop when rz <= tol2 * rz0 (on return: the tolerance the solve was stopped under)
+    double tol2_loose;   // ... or when rz <= tol2_loose * rz0 and the last two iterations lowered the
+    double q_abs;        // quadratic model by at most q_abs each (q_abs < 0: this rule is off)
+    double dq1, dq2;     // model decrease of the last and the last but one iteration (alpha r'z / 2)
     int iter;         // matvecs completed
     int max_iter;
     int done;
@@ -68,7 +71,9 @@ struct FusedPcg {
     PcgState* out;            // final state; pad = 1 on breakdown, 2 on exchange timeout
     double* flag_slot;        // receives pad as a double (a scalar slot the ranks sum), may be null
     double* flag_host;        // the same slot in pinned host memory, may be null
-    double tol2;
+    double tol2;              // stop when r'r <= tol2 r0'r0 ...
+    double tol2_loose;        // ... or when r'r <= tol2_loose r0'r0 and each of the last two iterations lowered
+    double q_abs;             // the quadratic model by at most q_abs (< 0: this rule is off)
     int max_iter;
     long long timeout_ticks;  // of the 100 MHz wall clock: any later poll
     long long admit_ticks;    // the first poll (all workgroups resident and started)
@@ -213,7 +218,7 @@ void launch_spmv_cm(const Dev& d, const double4* svec, const PcgState* state, hi
 // matvec kernels]  [update]; `cur` is the iteration parity (state and direction are double-buffered)
 int pcg_update_blocks(const Dev& d);
 int pcg_spmv_blocks(const Dev& d);
-void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st);
+void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st, double tol_loose = 0.0, double q_abs = -1.0);
 void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st);            // explicit mode
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);                 // implicit mode: direction only
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);    // implicit mode: q = U* p - qS

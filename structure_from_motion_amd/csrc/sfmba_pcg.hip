@@ -53,7 +53,7 @@ __device__ __forceinline__ double precond_row(const double* __restrict__ m, cons
 
 // x = 0, r = b, z = M^-1 r, p_old = 0, r'z partials; thread = (camera, row).
 template <int ND>
-__global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d, double tol, int max_iter) {
+__global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d, double tol, int max_iter, double tol_loose, double q_abs) {
     constexpr int kCams = cams_per_update_block<ND>();
     __shared__ double red[16];
     __shared__ double rs[kBlock];
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d, double tol, int max_
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         PcgState st;
         st.rz = 0.0; st.rz0 = 0.0; st.tol2 = tol * tol; st.iter = 0; st.max_iter = max_iter; st.done = 0; st.pad = 0; st.ticks = 0;
+        st.tol2_loose = tol_loose * tol_loose; st.q_abs = q_abs; st.dq1 = st.dq2 = 1e300;
         d.pcg[0] = st;
         d.pcg[1] = st;
     }
@@ -102,7 +103,11 @@ __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch)
         nx.done = !(rz > 0.0);                      // zero (or NaN) right-hand side
     } else {
         h.beta = rz / st.rz;
-        nx.done = !(rz > st.tol2 * st.rz0) || st.iter >= st.max_iter;
+        // (the model rule: the residual has passed the loose tolerance and the last two iterations
+        // each gained at most q_abs)
+        const bool small_gain = st.q_abs >= 0.0 && !(rz > st.tol2_loose * st.rz0) && st.dq1 <= st.q_abs && st.dq2 <= st.q_abs;
+        nx.done = !(rz > st.tol2 * st.rz0) || small_gain || st.iter >= st.max_iter;
+        if (small_gain && rz > st.tol2 * st.rz0) nx.tol2 = st.tol2_loose;
     }
     h.run = !nx.done;
     if (h.run) nx.iter = st.iter + 1;
@@ -246,6 +251,10 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_
     if (st.done) return;
     const double pq = block_total(d.dot_part, n_pq_parts, red);
     const double alpha = st.rz / pq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // what this iteration gains in the quadratic model
+        d.pcg[cur ^ 1].dq2 = st.dq1;
+        d.pcg[cur ^ 1].dq1 = 0.5 * alpha * st.rz;
+    }
     const int local = threadIdx.x / ND, k = threadIdx.x - ND * local;
     const int c = blockIdx.x * kCams + local;
     const bool act = local < kCams && c < d.n_cam;
@@ -546,6 +555,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
     }
 
     double gam = 0.0, gam0 = 0.0, gam_prev = 0.0, den_prev = 0.0;
+    double dq1 = 1e300, dq2 = 1e300, tol2_met = a.tol2;
     int it = 0, flag = 0;
     for (;;) {
         const int slot = it % kSlots;
@@ -585,14 +595,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
         if (it == 0) {
             gam0 = gam;
             if (!(gam > 0.0)) break;                        // zero (or NaN) right-hand side
-        } else if (!(gam > a.tol2 * gam0) || it >= a.max_iter) {
-            break;
+        } else {
+            const bool small_gain = a.q_abs >= 0.0 && !(gam > a.tol2_loose * gam0) && dq1 <= a.q_abs && dq2 <= a.q_abs;
+            if (small_gain && gam > a.tol2 * gam0) tol2_met = a.tol2_loose;
+            if (!(gam > a.tol2 * gam0) || small_gain || it >= a.max_iter) break;
         }
         // 1 / alpha = delta / gamma - beta / alpha_prev, i.e. den = delta - beta^2 den_prev
         const double beta = it ? gam / gam_prev : 0.0;
         const double den = del - beta * beta * den_prev;
         if (!(den > 0.0)) { flag = 1; break; }               // breakdown: caller falls back
         const double alpha = gam / den;
+        dq2 = dq1;
+        dq1 = 0.5 * alpha * gam;             // what this iteration gains in the quadratic model
         gam_prev = gam;
         den_prev = den;
 
@@ -696,7 +710,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_fused(FusedPcg a) {
     }
     if (blockIdx.x == 0 && tid == 0) {
         PcgState st;
-        st.rz = gam; st.rz0 = gam0; st.tol2 = a.tol2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
+        st.rz = gam; st.rz0 = gam0; st.tol2 = tol2_met; st.tol2_loose = a.tol2_loose; st.q_abs = a.q_abs; st.dq1 = dq1; st.dq2 = dq2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
         st.ticks = (long long)wall_clock64() - t_start;
         *a.out = st;
         if (a.flag_slot) *a.flag_slot = (double)flag;
@@ -857,6 +871,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
     };
 
     double gam = 0.0, gam0 = 0.0, gam_prev = 0.0, alpha_prev = 1.0;
+    double dq1 = 1e300, dq2 = 1e300, tol2_met = a.tol2;
     int it = 0, flag = 0;
     for (;;) {
         const int slot = it % kSlots;
@@ -951,13 +966,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
         if (it == 0) {
             gam0 = gam;
             if (!(gam > 0.0)) break;                        // zero (or NaN) right-hand side
-        } else if (!(gam > a.tol2 * gam0) || it >= a.max_iter) {
-            break;
+        } else {
+            const bool small_gain = a.q_abs >= 0.0 && !(gam > a.tol2_loose * gam0) && dq1 <= a.q_abs && dq2 <= a.q_abs;
+            if (small_gain && gam > a.tol2 * gam0) tol2_met = a.tol2_loose;
+            if (!(gam > a.tol2 * gam0) || small_gain || it >= a.max_iter) break;
         }
         const double beta = it ? gam / gam_prev : 0.0;
         const double den = del - (it ? beta * gam / alpha_prev : 0.0);
         if (!(den > 0.0)) { flag = 1; break; }               // breakdown: caller falls back
         const double alpha = gam / den;
+        dq2 = dq1;
+        dq1 = 0.5 * alpha * gam;             // what this iteration gains in the quadratic model
         gam_prev = gam;
         alpha_prev = alpha;
         if (lane < ND) {
@@ -984,7 +1003,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
     }
     if (blockIdx.x == 0 && tid == 0) {
         PcgState st;
-        st.rz = gam; st.rz0 = gam0; st.tol2 = a.tol2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
+        st.rz = gam; st.rz0 = gam0; st.tol2 = tol2_met; st.tol2_loose = a.tol2_loose; st.q_abs = a.q_abs; st.dq1 = dq1; st.dq2 = dq2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
         st.ticks = (long long)wall_clock64() - t_start;
         *a.out = st;
         if (a.flag_slot) *a.flag_slot = (double)flag;
@@ -1269,6 +1288,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     };
 
     double gam0 = 0.0, gam_prev = 0.0, alpha_prev = 1.0;
+    double dq1 = 1e300, dq2 = 1e300, tol2_met = a.tol2;
     int it = 0;
     double qa0 = 0.0;
     if (!flag) {
@@ -1411,13 +1431,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         if (it == 0) {
             gam0 = gam;
             if (!(gam > 0.0)) break;                        // zero (or NaN) right-hand side
-        } else if (!(gam > a.tol2 * gam0) || it >= a.max_iter) {
-            break;
+        } else {
+            const bool small_gain = a.q_abs >= 0.0 && !(gam > a.tol2_loose * gam0) && dq1 <= a.q_abs && dq2 <= a.q_abs;
+            if (small_gain && gam > a.tol2 * gam0) tol2_met = a.tol2_loose;
+            if (!(gam > a.tol2 * gam0) || small_gain || it >= a.max_iter) break;
         }
         const double beta = it ? gam / gam_prev : 0.0;
         const double den = del - (it ? beta * gam / alpha_prev : 0.0);
         if (!(den > 0.0)) { flag = 1; break; }               // breakdown: caller falls back
         const double alpha = gam / den;
+        dq2 = dq1;
+        dq1 = 0.5 * alpha * gam;             // what this iteration gains in the quadratic model
         gam_prev = gam;
         alpha_prev = alpha;
         if (mine && lane < ND) {
@@ -1446,7 +1470,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     }
     if (blockIdx.x == 0 && tid == 0) {
         PcgState st;
-        st.rz = gam; st.rz0 = gam0; st.tol2 = a.tol2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
+        st.rz = gam; st.rz0 = gam0; st.tol2 = tol2_met; st.tol2_loose = a.tol2_loose; st.q_abs = a.q_abs; st.dq1 = dq1; st.dq2 = dq2; st.iter = it; st.max_iter = a.max_iter; st.done = 1; st.pad = flag;
         st.ticks = (long long)wall_clock64() - t_start;
         *a.out = st;
         if (a.flag_slot) *a.flag_slot = (double)flag;
@@ -1486,9 +1510,9 @@ hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st) {
     return hipGetLastError();
 }
 
-void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st) {
-    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_init<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter);
-    else hipLaunchKernelGGL((k_pcg_init<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter);
+void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st, double tol_loose, double q_abs) {
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_init<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter, tol_loose, q_abs);
+    else hipLaunchKernelGGL((k_pcg_init<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, tol, max_iter, tol_loose, q_abs);
 }
 void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st) {
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_spmv_bsr<Bal::ND>), dim3(pcg_spmv_blocks(d)), dim3(kBlock), 0, st, d, cur);

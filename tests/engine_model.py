@@ -103,7 +103,7 @@ class Model:
 
 
 def lm_solve(prob, ftol=1e-4, xtol=1e-12, gtol=1e-8, max_iter=100, lam0=1e-4, pcg_tol=0.1,
-             pcg_max=500, dense=False, verbose=False, log=None):
+             pcg_max=500, dense=False, verbose=False, log=None, down=1.0 / 30.0):
     """Returns (model, info).  cost convention 0.5*||r||^2."""
     m = Model(prob)
     lam = lam0
@@ -203,7 +203,7 @@ def lm_solve(prob, ftol=1e-4, xtol=1e-12, gtol=1e-8, max_iter=100, lam0=1e-4, pc
             if rho > 1e-3 and np.isfinite(cost_new):
                 accepted = True
                 m.Q, m.t, m.X = Qn, tn, Xn
-                lam *= max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
+                lam *= max(down, 1.0 - (2.0 * rho - 1.0) ** 3)
                 lam = max(lam, 1e-12)
                 nu = 2.0
                 ft = actual < ftol * cost and rho > 0.25
