@@ -316,14 +316,20 @@ def main():
                    if ps.pcg_single_launch else "k_pcg_spmv_bsr"}
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (profiles/run_profile.sh -> profiles/traffic.json); null when the workload differs
-    traffic = None
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and args.shape == "venice" and args.scale == 1.0 and not bal and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from summarize import kernel_sources_digest
         with open(tpath) as f:
-            recorded = json.load(f).get("kernels", {})
-        for name, rec in recorded.items():          # template arguments follow the name: k_schur_pairs<Pinhole>
-            if name.split("<")[0] == kernel_name[dom]:
-                traffic = rec.get("hbm_bytes_per_launch")
+            record = json.load(f)
+        if record.get("kernel_sources_sha256") != kernel_sources_digest():
+            # the counters were taken from other kernels than the ones measured here
+            traffic_note = "profiles/traffic.json was recorded from other kernel sources: traffic withheld"
+        else:
+            for name, rec in record.get("kernels", {}).items():     # template arguments follow the name: k_schur_pairs<Pinhole>
+                if name.split("<")[0] == kernel_name[dom]:
+                    traffic = rec.get("hbm_bytes_per_launch")
     roof = {"bound": "hbm", "kernel": kernel_name[dom], "achieved": price(dom), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": price(dom) / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": families[dom]["avg_us"],
@@ -333,6 +339,8 @@ def main():
                               for f in single if f != dom},
             "schur_mode": "explicit" if ps.schur_mode == 2 else "implicit",
             "schur_pairs": int(ps.schur_pairs), "schur_blocks": int(ps.schur_blocks)}
+    if traffic_note:
+        roof["traffic_note"] = traffic_note
     if dom == "pairs" and not bal and families[dom]["avg_us"] > 0:
         # the pair kernel streams little (one index per pair, every point once) and computes much: its
         # other roof is the vector unit

@@ -31,8 +31,19 @@ def dehomogenize(h):
     return h[:, :-1] * scale[:, None]
 
 
-def triangulate(P1, P2, x1, x2):
-    """cv.triangulatePoints + convertPointsFromHomogeneous: (N, 3) points."""
+def dehomogenize_f32(h):
+    """The same for a float32 array, in float32 arithmetic as OpenCV does for CV_32F input:
+    scale = 1 / w (or 1), every coordinate times scale."""
+    h = np.asarray(h, np.float32)
+    w = h[:, -1]
+    scale = np.where(w != 0, np.float32(1.0) / np.where(w != 0, w, np.float32(1.0)), np.float32(1.0)).astype(np.float32)
+    return (h[:, :-1] * scale[:, None]).astype(np.float32)
+
+
+def triangulate(P1, P2, x1, x2, single=False):
+    """cv.triangulatePoints + convertPointsFromHomogeneous: (N, 3) points.  ``single``: the keypoints
+    were float32, so cv.triangulatePoints hands back its (double-computed) homogeneous points rounded
+    to float32 and the division happens in float32."""
     P1 = np.asarray(P1, float).reshape(3, 4)
     P2 = np.asarray(P2, float).reshape(3, 4)
     x1 = np.asarray(x1, float).reshape(-1, 2)
@@ -40,6 +51,8 @@ def triangulate(P1, P2, x1, x2):
     A = np.stack([x1[:, 0:1] * P1[2] - P1[0], x1[:, 1:2] * P1[2] - P1[1],
                   x2[:, 0:1] * P2[2] - P2[0], x2[:, 1:2] * P2[2] - P2[1]], axis=1)       # (N, 4, 4)
     _, _, Vt = np.linalg.svd(A)
+    if single:
+        return dehomogenize_f32(Vt[:, 3, :].astype(np.float32))
     return dehomogenize(Vt[:, 3, :])
 
 
@@ -57,12 +70,11 @@ def triangulate_points(K, t1, R1, t2, R2, x1, x2):
     if len(x1) < 8:
         return None
     P1, P2 = projection(K, R1, t1), projection(K, R2, t2)
-    X = triangulate(P1, P2, x1, x2)
+    # cv.triangulatePoints creates its output in the type of projPoints1 (the arithmetic is double
+    # either way): float32 keypoints give float32 homogeneous points, de-homogenised in float32, and
+    # the error test below (utils.py:199-208) sees those rounded points
+    X = triangulate(P1, P2, x1, x2, single=np.asarray(x1).dtype == np.float32)
     if reprojection_errors(P1, X, x1).mean() < 55 and reprojection_errors(P2, X, x2).mean() < 55:
-        # cv.triangulatePoints creates its output in the type of projPoints1 (the arithmetic is
-        # double either way); float32 keypoints therefore give float32 points
-        if np.asarray(x1).dtype == np.float32:
-            X = X.astype(np.float32)
         return X.reshape(-1, 1, 3)
     return None
 

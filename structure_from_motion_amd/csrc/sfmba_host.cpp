@@ -1156,7 +1156,7 @@ SchurPlan sfmba::plan_schur(H* h) {
     // iterated on: the reference's own workloads (11 views, a ring of 47) have 66 to 282 unknowns,
     // an exact step lets the damping fall to its floor, and the Gauss-Newton steps that follow are
     // what SciPy's trust-region solver takes on them (scipy/optimize/_lsq/trf.py:473-499).
-    int auto_dense_dim = 320;
+    int auto_dense_dim = 288;          // up to 48 six-number cameras: nine block rows of the single-launch factorisation
     if (const char* e = getenv("SFMBA_DENSE_AUTO_DIM")) auto_dense_dim = atoi(e);
     h->dense_auto = lin == SFMBA_SOLVER_AUTO && mode != 1 && dense_padded((int)std::min<int64_t>(n_red, 1 << 20)) <= auto_dense_dim;
     const bool want_dense = lin == SFMBA_SOLVER_DENSE || h->dense_auto;
@@ -1988,8 +1988,10 @@ int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
         delete h;
         return SFMBA_ERR_HIP;
     }
-    // this device's copy of the scratch array of sfmba_triangulate_noalloc (once per device)
-    if (scratch_ptr(dev, &h->scratch) != hipSuccess) { delete h; return SFMBA_ERR_HIP; }
+    // this device's copy of the scratch array of sfmba_triangulate_noalloc (once per device).  A
+    // handle that never takes that entry point does not need it: a failure here (return code
+    // checked in scratch_ptr) leaves the pointer null and is reported by that entry point alone.
+    if (scratch_ptr(dev, &h->scratch) != hipSuccess) { h->scratch = nullptr; (void)hipGetLastError(); }
     if (hipHostMalloc((void**)&h->pcg_host, 2 * sizeof(PcgState), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->scalars_host, SLOT_COUNT * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&h->pcg_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -2182,7 +2184,13 @@ int sfmba_triangulate_noalloc(sfmba_handle* h, int64_t n, const double* P1, cons
                  "(SFMBA_TRIANGULATE_NOALLOC_MAX); use sfmba_triangulate", (long long)n, (long long)kNoallocMax);
         if (n == 0) return;
         HIP_TRY(hipSetDevice(h->device));
-        unsigned char* base = h->scratch;      // resolved for this device in sfmba_create
+        if (!h->scratch) {                     // not resolved in sfmba_create: once more, and say why not
+            const hipError_t e = scratch_ptr(h->device, &h->scratch);
+            if (e != hipSuccess || !h->scratch)
+                fail(SFMBA_ERR_HIP, "sfmba_triangulate_noalloc: the library's scratch array has no address on device %d (%s)",
+                     h->device, hipGetErrorString(e));
+        }
+        unsigned char* base = h->scratch;      // this device's address of the array, never the array's name
         double2* d1 = reinterpret_cast<double2*>(base + kScrX1);
         double2* d2 = reinterpret_cast<double2*>(base + kScrX2);
         double* dX = reinterpret_cast<double*>(base + kScrX);

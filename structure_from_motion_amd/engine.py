@@ -313,7 +313,9 @@ class Engine:
         """Batched two-view linear triangulation: (X n x 3, err1, err2) for 3x4 projection matrices
         P1, P2 and n x 2 pixel coordinates x1, x2 (see sfmba_triangulate).  `noalloc` takes the
         entry point that stages through the library's fixed device array instead of allocating
-        (at most TRIANGULATE_NOALLOC_MAX correspondences per call)."""
+        (at most TRIANGULATE_NOALLOC_MAX correspondences per call).  That array is one per GPU,
+        shared by every engine on it and not locked by the library: calls with ``noalloc`` that
+        overlap on one GPU (two threads, two engines) race - the caller serialises them."""
         P1 = _f64(P1).reshape(3, 4); P2 = _f64(P2).reshape(3, 4)
         x1 = _f64(x1).reshape(-1, 2); x2 = _f64(x2).reshape(-1, 2)
         n = x1.shape[0]

@@ -42,14 +42,24 @@ def triangulate_points(K, t1, R1, t2, R2, x1, x2, print_error=False):
     logging.info("Triangulating 3D points...")
     if len(x1) < 8:
         return None
-    X, error1, error2 = _eng().triangulate(_projection(K, R1, t1), _projection(K, R2, t2), x1, x2)
+    P1, P2 = _projection(K, R1, t1), _projection(K, R2, t2)
+    X, error1, error2 = _eng().triangulate(P1, P2, x1, x2)
+    if np.asarray(x1).dtype == np.float32:
+        # cv.triangulatePoints hands its homogeneous points back in the type of the keypoints
+        # (computed in double either way) and cv.convertPointsFromHomogeneous then divides in that
+        # type: the unit singular vector (X, 1) / |(X, 1)| rounded to float32, times 1 / w in float32.
+        # The error test sees those rounded points, as the reference's does (utils.py:197-208).
+        # (Parity with OpenCV itself is unpinned: it is not installed where this was written.)
+        h = np.hstack((X, np.ones((len(X), 1)))) / np.sqrt(1.0 + np.sum(X * X, axis=1))[:, None]
+        h = np.where(np.isfinite(h), h, 0.0).astype(np.float32)
+        w = h[:, 3]
+        scale = np.where(w != 0, np.float32(1.0) / np.where(w != 0, w, np.float32(1.0)), np.float32(1.0)).astype(np.float32)
+        X = (h[:, :3] * scale[:, None]).astype(np.float32)
+        error1 = _eng().point_errors(P1, X, x1)
+        error2 = _eng().point_errors(P2, X, x2)
     if print_error:
         print(np.mean(error1), np.mean(error2))
     if np.mean(error1) < 55 and np.mean(error2) < 55:
-        # cv.triangulatePoints hands the points back in the type of the keypoints it was given
-        # (computed in double either way); the error test above uses the unrounded points
-        if np.asarray(x1).dtype == np.float32:
-            X = X.astype(np.float32)
         return X.reshape(-1, 1, 3)
     return None
 

@@ -271,7 +271,7 @@ def test_unobserved_camera_and_point_stay_where_they_are():
 
 
 def test_dense_cholesky_is_the_fallback_when_pcg_runs_out_of_iterations():
-    # (more than the 53 cameras up to which the library factors the camera system to begin with)
+    # (more than the 48 cameras up to which the library factors the camera system to begin with)
     p = syn.make_problem(60, 500, 2000, seed=4, window=6)
     ref = o.solve_reference(p)
     with make_engine(p, pcg_max_iter=1, pcg_rtol=1e-8) as eng:      # AUTO: PCG first
@@ -300,7 +300,7 @@ def test_dense_fallback_on_a_handle_that_held_a_smaller_problem():
 
 
 def test_small_camera_systems_are_factored_and_start_undamped():
-    """Left to choose, up to 53 cameras are solved by the single-launch Cholesky with Gauss-Newton
+    """Left to choose, up to 48 cameras are solved by the single-launch Cholesky with Gauss-Newton
     steps from the start; the multi-launch factorisation gives the same steps."""
     g = load_golden("shuffled_9_200_700")
     with make_engine(g) as eng:
