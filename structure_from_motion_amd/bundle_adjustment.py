@@ -256,7 +256,7 @@ def _reusable_rows(wpSet, ids, feats, view_idx):
     equal the shallow copies taken when they were packed - same length, and entry by entry the very
     same keypoint-array objects and equal view ids (so a row re-bound through ``.at``, an entry
     replaced inside a list, or a list extended as in WorldPoints.py:54-57 is packed afresh, from the
-    first such row on); and 512 rows spread over the table plus its last 64 pack to the same
+    first such row on); and 192 rows spread over the table plus its last 64 pack to the same
     numbers again.  What this cannot see is a number overwritten INSIDE a keypoint array that was
     packed before, in a row outside that sample; a caller who does that sets ``SFMBA_REPACK=1``."""
     try:
@@ -276,7 +276,7 @@ def _reusable_rows(wpSet, ids, feats, view_idx):
         m = min(_first_difference(ids[:m], rec.ids), _first_difference(feats[:m], rec.feats))
         if m == 0:
             return None
-    sample = np.unique(np.concatenate((np.linspace(0, m - 1, min(m, 512)).astype(np.int64), np.arange(max(0, m - 64), m))))
+    sample = np.unique(np.concatenate((np.linspace(0, m - 1, min(m, 192)).astype(np.int64), np.arange(max(0, m - 64), m))))
     try:
         cam, uv = _pack_rows([ids[i] for i in sample], [feats[i] for i in sample], view_idx)
     except KeyError:
@@ -450,17 +450,26 @@ class BundleAdjustment:
         t_start = time.perf_counter()
         poses, points_3d = self._poses, self._points_3d
         self.wpSet.world_points = points_3d
-        ci2 = np.asarray(self.camera_indices).reshape(-1, 2)
-        uv2 = np.asarray(self.points_2d, dtype=np.float64).reshape(-1, 2, 2)
+        ci2 = np.asarray(self.camera_indices, dtype=np.int64).reshape(-1, 2)
+        uv_flat = np.asarray(self.points_2d, dtype=np.float64).reshape(-1, 2)        # entry 2 * row + slot
+        # every (row, slot) entry grouped by its view with one stable sort (entries of a view then
+        # come in correspondence order); a row naming the view twice counts once, as its first entry
+        entry_view = ci2.ravel()
+        entries = np.arange(entry_view.size)
+        if len(ci2):
+            keep = np.ones(entry_view.size, dtype=bool)
+            keep[1::2] = ci2[:, 1] != ci2[:, 0]
+            entries, entry_view = entries[keep], entry_view[keep]
+        n_views = len(self.view_idx)
+        key = entry_view.astype(np.uint16) if n_views < 65536 else entry_view    # (16-bit keys: a radix sort)
+        order = entries[np.argsort(key, kind="stable")]
+        bounds = np.concatenate(([0], np.cumsum(np.bincount(entry_view, minlength=n_views))))
         for j, view in enumerate(self.completed_views):
             view.rotation = poses[j, :9].reshape(3, 3)
             view.translation = poses[j, 9:].reshape(3, 1)
             k = self.view_idx[view.id]
-            first = ci2[:, 0] == k
-            second = (ci2[:, 1] == k) & ~first           # a row naming the view twice counts once, as its first entry
-            rows = np.flatnonzero(first | second)
-            uv = np.where(first[rows, None], uv2[rows, 0], uv2[rows, 1])
-            view.world_points = np.hstack((uv, points_3d[rows])) if rows.size else np.empty((0, 5))
+            mine = order[bounds[k]:bounds[k + 1]]
+            view.world_points = np.hstack((uv_flat[mine], points_3d[mine >> 1])) if mine.size else np.empty((0, 5))
             if print_error:
                 print(f"Reprojection error for image{getattr(view, 'name', view.id)} is {self.reprojection_error[k]}")
         self.timings["write_back"] = time.perf_counter() - t_start

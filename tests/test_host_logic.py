@@ -146,7 +146,7 @@ def test_view2idx_reuses_what_it_packed_for_a_growing_table(tmp_path, monkeypatc
         _check_against_reference(b, views[:k + 1], wp.correspondences)
         # first call: all 50 rows; later: the sample that verifies the old rows (all of them in a
         # table this small), then the 50 new rows on their own
-        assert packed == ([50] if k == 1 else [50 * (k - 1), 50])
+        assert packed == ([50] if k == 1 else [len(np.unique(np.r_[np.linspace(0, 50 * (k - 1) - 1, min(50 * (k - 1), 192)).astype(int), np.arange(max(0, 50 * (k - 1) - 64), 50 * (k - 1))])), 50])
     # a row re-bound through .at, as WorldPoints.py:54-57 does for redundant views ...
     new_uv = [np.array([1.5, 2.5]), np.array([3.5, 4.5])]
     wp.correspondences.at[70, "FeatureIndex"] = new_uv
@@ -181,3 +181,30 @@ def test_fun_cache_compares_contents_at_memory_speed():
     b[1][-1, 1] += 1e-9                                     # one number in the last chunk
     assert not ba._same_arrays(list(zip(a, b)))
     assert not ba._same_arrays([(a[0], a[0].astype(np.int32))]) and not ba._same_arrays([(a[0], a[0][:-1])])
+
+
+def test_write_back_tables_equal_the_reference_loops(tmp_path, monkeypatch):
+    """write_back cuts every view's [u, v, X, Y, Z] table out of the packed arrays with one sort;
+    the reference walks the correspondences per view (view.py:121-132 update_world_points)."""
+    monkeypatch.chdir(tmp_path)
+    views, rows, rng = _growing_table(n_views=5, per_pair=30, seed=8)
+    corr = pd.concat(rows, ignore_index=True)
+    corr.at[3, "ViewId"] = ["id2", "id2"]                   # a row naming one view twice counts once, as its first entry
+    corr.at[9, "ViewId"] = ["id4", "id0"]
+    pts = rng.normal(size=(len(corr), 3))
+    wp = FakeWorldPoints(pts, corr)
+    b = ba.BundleAdjustment(wp, np.eye(3), np.zeros((1, 5)), views)
+    b.view2idx()
+    b._poses = rng.normal(size=(5, 12))
+    b._points_3d = pts + 0.5
+    b.reprojection_error = np.arange(5.0)
+    b.write_back(print_error=False)
+    assert wp.world_points is b._points_3d
+    for j, view in enumerate(views):
+        assert np.array_equal(view.rotation, b._poses[j, :9].reshape(3, 3)) and view.translation.shape == (3, 1)
+        want = []
+        for i, row in corr.iterrows():                      # the reference's loop
+            if view.id in row["ViewId"]:
+                k = row["ViewId"].index(view.id)
+                want.append(np.concatenate((row["FeatureIndex"][k], b._points_3d[i])))
+        assert np.array_equal(view.world_points, np.array(want).reshape(-1, 5))
