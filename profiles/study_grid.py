@@ -34,6 +34,7 @@ PROBLEMS = {"venice": lambda: syn.make_shape("venice", seed=0),
             "ring47": lambda: syn.make_problem(47, 1400, 2800, seed=13, window=3),
             "ladybug": lambda: syn.make_shape("ladybug", seed=0),
             "fountain": lambda: syn.make_shape("fountain", seed=0),
+            "final": lambda: syn.make_shape("final", seed=0),
             "final0.05": lambda: syn.make_shape("final", seed=0, scale=0.05),
             "final0.2": lambda: syn.make_shape("final", seed=0, scale=0.2),
             "venice0.02": lambda: syn.make_shape("venice", seed=0, scale=0.02),

@@ -846,6 +846,8 @@ void do_solve(H* h, sfmba_stats* out) {
     // iteration), and a step computed from a point that turns out to satisfy gtol is dropped.
     bool lin_pending = false;
     for (int it = 0; it < max_it && status < 0; ++it) {
+        const int pcg_before = st.pcg_iterations;
+        const int64_t coarse_before = h->coarse_solves;
         if (!rtol_schedule.empty() && !(o.pcg_rtol > 0))
             h->solve_rtol = rtol_schedule[std::min<size_t>(st.iterations, rtol_schedule.size() - 1)];
         h->model_gain_floor = gain_fraction >= 0.0 ? gain_fraction * ftol * cost : -1.0;
@@ -945,7 +947,8 @@ void do_solve(H* h, sfmba_stats* out) {
         const bool ft = actual < ftol * cost && rho > 0.25;
         const bool xt = step_norm < xtol * (xtol + x_norm);
         if (o.verbose >= 3 && o.rank <= 0)
-            emit(h, "  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e\n", it, cost, cost_new, rho, lambda, step_norm);
+            emit(h, "  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e pcg %d%s\n", it, cost, cost_new, rho, lambda, step_norm,
+                 st.pcg_iterations - pcg_before, h->coarse_solves > coarse_before ? " (two-level)" : "");
         if (rho > 1e-3) {
             h->cur ^= 1;
             ++accepted;

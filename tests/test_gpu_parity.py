@@ -513,3 +513,38 @@ def test_forms_of_the_point_major_passes_agree(default_variant, env):
         assert a["it"] == b["it"] and abs(a["pcg"] - b["pcg"]) <= 2
         assert abs(a["cost"] - b["cost"]) <= 1e-11 * a["cost"]
         assert abs(a["c0"] - b["c0"]) <= 1e-9 and abs(a["x0"] - b["x0"]) <= 1e-9
+
+
+@pytest.mark.parametrize("cams,pts,obs,window", [(120, 4000, 18000, 8), (30, 1500, 6000, 6)])
+def test_poor_starts_reach_scipys_cost(cams, pts, obs, window):
+    """Starts ten times further from the solution than the fixtures' (rotations off by 3 degrees,
+    translations and points by a tenth of the scene): the PCG-solved 120-camera problem and the
+    factored 30-camera one both end at or below SciPy's cost under the reference's tolerances.
+    (With the residual rule alone an inexact step could end such a run on the ftol rule far from the
+    minimum: the linear solves follow what the outer stopping rule can still see.)"""
+    p = syn.make_problem(cams, pts, obs, seed=11, window=window, rot_sigma=0.05, trans_sigma=0.1, point_sigma=0.1)
+    ref = o.solve_reference(p)
+    with make_engine(p) as eng:
+        st = eng.solve()
+    assert st.status > 0 and st.final_cost <= ref["cost"] * (1 + 1e-6)
+    assert st.linear_solver == (2 if cams <= 48 else 1)
+
+
+def test_pcg_model_rule_is_off_when_the_tolerance_is_given():
+    """pcg_rtol in the options means the residual rule alone, exactly as before: the tighter the
+    tolerance, the more iterations, and the iteration count of a given tolerance does not depend on
+    ftol (which the model rule scales with)."""
+    p = syn.make_problem(120, 4000, 18000, seed=12, window=8)
+    its = []
+    for tol in (1e-1, 1e-3, 1e-6):
+        with make_engine(p, pcg_rtol=tol, max_iterations=1) as eng:
+            its.append(eng.solve().pcg_iterations)
+    assert its[0] < its[1] < its[2]
+    with make_engine(p, pcg_rtol=1e-3, max_iterations=1, ftol=1e-12) as eng:
+        assert eng.solve().pcg_iterations == its[1]
+    # left open, the first solve of a run stops between the loose and the tight tolerance
+    with make_engine(p, max_iterations=1) as eng:
+        auto = eng.solve().pcg_iterations
+    with make_engine(p, pcg_rtol=0.03, max_iterations=1) as eng:
+        loose = eng.solve().pcg_iterations
+    assert loose <= auto <= its[1]
