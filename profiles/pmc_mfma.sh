@@ -14,14 +14,14 @@ from collections import defaultdict
 out = sys.argv[1]
 dur = defaultdict(list)
 for r in csv.DictReader(open(glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)[0])):
-    dur[r["Kernel_Name"].split("(")[0].replace("sfmba::", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    dur[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("sfmba::", "").replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(glob.glob(os.path.join(out, "pmc", "**", "*counter_collection.csv"), recursive=True)[0])):
-    acc[r["Kernel_Name"].split("(")[0].replace("sfmba::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("sfmba::", "").replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = ["SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]
 print("| kernel | launches | avg us | total ms | " + " | ".join(names) + " | MFMA util % (busy / (GUI_ACTIVE x 1024 SIMDs)) |")
 print("|---|---|---|---|" + "---|" * (len(names) + 1))
-for k in ("k_chol_diag", "k_chol_panel", "k_chol_solve", "k_bsr_to_dense", "k_schur_pairs"):
+for k in ("k_chol_flow", "k_chol_prepare", "k_chol_diag", "k_chol_panel", "k_chol_back", "k_bsr_to_dense", "k_schur_pairs"):
     if k not in dur:
         continue
     v = acc[k]

@@ -16,7 +16,7 @@ out = sys.argv[1]
 path = glob.glob(os.path.join(out, "pmc_sq", "**", "*counter_collection.csv"), recursive=True)[0]
 acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(path)):
-    k = r["Kernel_Name"].split("(")[0].replace("sfmba::", "")
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("sfmba::", "").replace("void ", "")
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS"]
 print("| kernel | n | " + " | ".join(names) + " |")

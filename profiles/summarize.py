@@ -26,7 +26,7 @@ def find(root, pattern):
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name.replace("sfmba::", "").replace("void ", "").strip()
 
 
