@@ -243,13 +243,21 @@ __global__ __launch_bounds__(kBlock) void k_coarse_restrict(Dev d, Coarse k, int
     if (slot < kSlotsOf7) {
         double acc = 0.0;
         const int hi = k.cl_ptr[I + 1];
-        for (int c = k.cl_ptr[I] + slot; c < hi; c += kSlotsOf7) {
-            const double* __restrict__ z = k.Z + (kVecs * (size_t)c + a) * ND;
-            const double* __restrict__ r = d.pr + ND * (size_t)c;
-            double s = 0.0;
+        // four cameras of a thread at a time, their loads requested together (clamped, masked)
+        for (int c = k.cl_ptr[I] + slot; c < hi; c += 4 * kSlotsOf7) {
+            double s[4];
 #pragma unroll
-            for (int i = 0; i < ND; ++i) s += z[i] * r[i];
-            acc += s;
+            for (int u = 0; u < 4; ++u) {
+                const int cc = min(c + u * kSlotsOf7, hi - 1);
+                const double* __restrict__ z = k.Z + (kVecs * (size_t)cc + a) * ND;
+                const double* __restrict__ r = d.pr + ND * (size_t)cc;
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < ND; ++i) t += z[i] * r[i];
+                s[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += c + u * kSlotsOf7 < hi ? s[u] : 0.0;
         }
         part[slot][a] = acc;
     }
@@ -279,25 +287,40 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
     const int nrows = min(kVecs * (k.cam_cl[c1] - I0 + 1), 2 * kVecs);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     {
-        // wavefront w takes rows w, w + 4, w + 8, w + 12: their loads are issued together
-        constexpr int kRowsPerWave = (2 * kVecs + kBlock / 64 - 1) / (kBlock / 64);
+        // y = D Einv rc for the workgroup's (up to 14) rows: thread t takes columns t, t + 256, ...
+        // of every row, so that all loads of a round are independent and requested together; the
+        // sums of a row meet in a wavefront reduction and four LDS words
+        constexpr int kRows = 2 * kVecs;
+        __shared__ double ypart[kBlock / 64][kRows];
         const double* __restrict__ e0 = k.Einv + (size_t)(kVecs * I0) * k.n_pad;
-        double s[kRowsPerWave];
+        double s[kRows];
 #pragma unroll
-        for (int q = 0; q < kRowsPerWave; ++q) s[q] = 0.0;
-        for (int j = lane; j < k.n_pad; j += 64) {
-            const double rj = k.rc[j];
+        for (int q = 0; q < kRows; ++q) s[q] = 0.0;
+        for (int j = threadIdx.x; j < k.n_pad; j += 2 * kBlock) {
+            // (n_pad is a multiple of 32, not of the workgroup: the second column is clamped and masked)
+            const int j2 = min(j + kBlock, k.n_pad - 1);
+            const double rj = k.rc[j], rj2 = j + kBlock < k.n_pad ? k.rc[j2] : 0.0;
+            double e[kRows], e2[kRows];
 #pragma unroll
-            for (int q = 0; q < kRowsPerWave; ++q) {
-                const int row = w + (kBlock / 64) * q;
-                if (row < nrows) s[q] += e0[(size_t)row * k.n_pad + j] * rj;
+            for (int q = 0; q < kRows; ++q) {
+                const double* __restrict__ row = e0 + (size_t)(q < nrows ? q : 0) * k.n_pad;
+                e[q] = row[j];
+                e2[q] = row[j2];
             }
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) s[q] += e[q] * rj + e2[q] * rj2;
         }
 #pragma unroll
-        for (int q = 0; q < kRowsPerWave; ++q) {
-            const int row = w + (kBlock / 64) * q;
+        for (int q = 0; q < kRows; ++q) {
             const double t = wave_sum(s[q]);
-            if (row < nrows && lane == 0) y[row] = k.scale[kVecs * I0 + row] * t;
+            if (lane == 0) ypart[w][q] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < nrows) {
+            double t = ypart[0][threadIdx.x];
+#pragma unroll
+            for (int v = 1; v < kBlock / 64; ++v) t += ypart[v][threadIdx.x];
+            y[threadIdx.x] = k.scale[kVecs * I0 + threadIdx.x] * t;
         }
     }
     __syncthreads();

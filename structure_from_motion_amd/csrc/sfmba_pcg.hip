@@ -31,8 +31,18 @@ int pcg_spmv_blocks(const Dev& d) { return cdiv(d.n_cam, kCamsPerSpmvBlock); }
 
 // Sum of n partials by the whole workgroup, result broadcast to every thread (fixed order).
 __device__ __forceinline__ double block_total(const double* __restrict__ part, int n, double* scratch) {
+    // eight loads of a thread are requested together (indices clamped into the array, what lies
+    // beyond it masked afterwards): a loop that waits for every load costs a memory round trip per
+    // 256 partials, and thousands of partials arrive per iteration at ten thousand cameras
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    const int step = blockDim.x;
+    for (int i = threadIdx.x; i < n; i += 8 * step) {
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = part[min(i + j * step, n - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += i + j * step < n ? a[j] : 0.0;
+    }
     const double s = block_sum(v, scratch);
     __syncthreads();
     if (threadIdx.x == 0) scratch[0] = s;
