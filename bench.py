@@ -358,6 +358,25 @@ def main():
                  "replicated_pcg_ms_per_solve": families["bsr"]["total_ms"] + families["pcg_vec"]["total_ms"]
                  if ps.schur_mode == 2 else None,
                  "profiled_solve_ms": 1e3 * ps.solve_seconds}
+        if ps.schur_mode == 2:
+            # modelled bytes every rank hands to a collective (before the factor 2 (N - 1) / N of a
+            # ring all-reduce): the form that is built - all upper blocks all-reduced once per LM
+            # iteration, PCG replicated, no collective inside it - and the form that is not built, in
+            # which every rank keeps the blocks of its own points and the product q = S p is summed
+            # over the ranks in every PCG iteration
+            cd, cv = (9, 54) if bal else (6, 27)
+            n_c, blocks = int(p["n_cameras"]), int(ps.schur_blocks)
+            lm, pcg = max(1, ps.iterations), ps.pcg_iterations
+            small = 8 * (cv * n_c + world) + 8 * 16
+            multi["model"] = {
+                "replicated_matrix (built)": {"collectives_per_lm_iteration": 3,
+                                              "bytes_per_lm_iteration": small + 8 * (cd * cd * blocks + cv * n_c),
+                                              "collectives_per_pcg_iteration": 0},
+                "matrix_split_by_points (not built)": {"collectives_per_lm_iteration": 3,
+                                                       "bytes_per_lm_iteration": small + 8 * (cd * cd + cv) * n_c,
+                                                       "collectives_per_pcg_iteration": 1,
+                                                       "bytes_per_pcg_iteration": 8 * cd * n_c,
+                                                       "pcg_iterations_per_lm_iteration": pcg / lm}}
 
     eng.close()
     if dist is not None:
