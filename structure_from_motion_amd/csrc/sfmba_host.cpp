@@ -822,6 +822,13 @@ void do_solve(H* h, sfmba_stats* out) {
             if (v > 0) rtol_schedule.push_back(v);
             q = *end == ',' ? end + 1 : end;
         }
+    // test hook: SFMBA_CHOL_TEST_FAIL="k:v" makes the k-th single-launch factorisation of a solve
+    // count as failed on every rank - v = 1 not positive definite, v = 2 given up - so that the two
+    // recoveries below run without a matrix that provokes them
+    int chol_fail_at = -1, chol_fail_kind = 0, chol_launches = 0;
+    if (const char* e = getenv("SFMBA_CHOL_TEST_FAIL")) {
+        if (sscanf(e, "%d:%d", &chol_fail_at, &chol_fail_kind) != 2) chol_fail_at = -1;
+    }
     h->profile = o.profile != 0;
     if (const char* e = getenv("SFMBA_PROFILE")) h->profile = atoi(e) != 0;
     auto t0 = std::chrono::steady_clock::now();
@@ -874,9 +881,10 @@ void do_solve(H* h, sfmba_stats* out) {
         }
         if (pending && pending_dense) {
             // the factorisation's failure word, summed over the ranks (which all factor the same matrix)
-            const double flag = sc[SLOT_PCGFLAG];
+            const double all_ranks = h->has_comm() ? (double)o.nranks : 1.0;
+            double flag = sc[SLOT_PCGFLAG];
+            if (chol_launches++ == chol_fail_at) flag = chol_fail_kind == 1 ? all_ranks : all_ranks + 1.0;
             if (flag != 0.0) {
-                const double all_ranks = h->has_comm() ? (double)o.nranks : 1.0;
                 if (flag != all_ranks) {
                     // given up somewhere (time limit): every rank takes the chain of launches from now on
                     h->dense_flow = false;

@@ -317,6 +317,29 @@ def test_small_camera_systems_are_factored_and_start_undamped():
     assert chain.iterations == st.iterations and abs(chain.final_cost - st.final_cost) <= 1e-9 * st.final_cost
 
 
+@pytest.mark.parametrize("kind", [1, 2])
+def test_recoveries_of_the_single_launch_factorisation(kind, monkeypatch):
+    """What the LM loop does when the single-launch factorisation reports a matrix that is not
+    positive definite at the current damping (1: raise the damping, factor again) or gives up on
+    its time limit (2: the chain of launches from then on), provoked through the library's test
+    hook at the second factorisation of a solve: the run still ends at SciPy's cost, with one
+    factorisation more than it has iterations."""
+    g = load_golden("shuffled_9_200_700")
+    with make_engine(g) as eng:
+        plain = eng.solve()
+    monkeypatch.setenv("SFMBA_CHOL_TEST_FAIL", f"1:{kind}")
+    with make_engine(g) as eng:
+        st = eng.solve()
+        again = eng.solve() if kind == 2 else None
+    assert st.status > 0 and st.linear_solver == 2 and st.pcg_iterations == 0
+    assert st.n_dense == st.iterations + 1
+    assert st.final_cost <= float(g["ref_cost"]) * (1 + 1e-6)
+    if kind == 2:
+        # same steps from either implementation; the handle stays on the chain of launches
+        assert st.iterations == plain.iterations and abs(st.final_cost - plain.final_cost) <= 1e-9 * plain.final_cost
+        assert again.status > 0
+
+
 def test_inputs_are_not_modified_and_solve_is_deterministic():
     g = load_golden("rho2_11_300_600")
     keep = {k: g[k].copy() for k in ("camera_params", "points_3d", "camera_indices", "point_indices", "points_2d")}
