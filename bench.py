@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--pcg-mode", type=int, default=0, help="0 auto, 1 two launches per iteration, 2 single launch")
     ap.add_argument("--pcg-coarse", type=int, default=0,
                     help="two-level PCG preconditioner: 0 default policy, -1 off, k clusters of k cameras")
+    ap.add_argument("--matrix-split", type=int, default=0,
+                    help="N > 1: 0/1 reduced matrix replicated on every rank, 2 split by points (a collective per PCG iteration)")
     ap.add_argument("--through-class", action="store_true",
                     help="also time BundleAdjustment.optimize() whole, view by view, on a growing problem of --shape "
                          "(fountain or temple: two observations per point), reported as optimize_class_seconds")
@@ -212,7 +214,7 @@ def main():
     else:
         p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
     solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode, pcg_coarse=args.pcg_coarse,
-                       camera_model=args.camera_model)
+                       camera_model=args.camera_model, matrix_split=args.matrix_split)
     eng = Engine(device=local_rank, rank=rank, nranks=world, **solver_opts)
     t0 = time.time()
     eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
@@ -357,22 +359,23 @@ def main():
                  "collective_ms_per_solve": families["comm"]["total_ms"],
                  "replicated_pcg_ms_per_solve": families["bsr"]["total_ms"] + families["pcg_vec"]["total_ms"]
                  if ps.schur_mode == 2 else None,
-                 "profiled_solve_ms": 1e3 * ps.solve_seconds}
+                 "profiled_solve_ms": 1e3 * ps.solve_seconds,
+                 "reduced_matrix": "split by points" if args.matrix_split == 2 and ps.schur_mode == 2 and args.linear_solver != 2 else "replicated"}
         if ps.schur_mode == 2:
             # modelled bytes every rank hands to a collective (before the factor 2 (N - 1) / N of a
-            # ring all-reduce): the form that is built - all upper blocks all-reduced once per LM
-            # iteration, PCG replicated, no collective inside it - and the form that is not built, in
-            # which every rank keeps the blocks of its own points and the product q = S p is summed
-            # over the ranks in every PCG iteration
+            # ring all-reduce): the default form - all upper blocks all-reduced once per LM iteration,
+            # PCG replicated, no collective inside it - and the split form (options.matrix_split = 2),
+            # in which every rank keeps the blocks of its own points and the product q = S p is
+            # summed over the ranks in every PCG iteration
             cd, cv = (9, 54) if bal else (6, 27)
             n_c, blocks = int(p["n_cameras"]), int(ps.schur_blocks)
             lm, pcg = max(1, ps.iterations), ps.pcg_iterations
             small = 8 * (cv * n_c + world) + 8 * 16
             multi["model"] = {
-                "replicated_matrix (built)": {"collectives_per_lm_iteration": 3,
+                "replicated_matrix (default)": {"collectives_per_lm_iteration": 3,
                                               "bytes_per_lm_iteration": small + 8 * (cd * cd * blocks + cv * n_c),
                                               "collectives_per_pcg_iteration": 0},
-                "matrix_split_by_points (not built)": {"collectives_per_lm_iteration": 3,
+                "matrix_split_by_points (--matrix-split 2)": {"collectives_per_lm_iteration": 3,
                                                        "bytes_per_lm_iteration": small + 8 * (cd * cd + cv) * n_c,
                                                        "collectives_per_pcg_iteration": 1,
                                                        "bytes_per_pcg_iteration": 8 * cd * n_c,

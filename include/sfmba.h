@@ -117,6 +117,21 @@ typedef struct sfmba_options {
      * threads (the first implementation, kept as the layout the GPU path is tested against; both
      * produce the same arrays, so solves are bit-identical). */
     int32_t setup_mode;
+    /* How a partitioned solve (nranks > 1) holds the explicit reduced matrix:
+     *   1 = replicated: the upper blocks of all ranks are summed by one all-reduce per LM iteration
+     *       (36 doubles per block) and every rank runs the same PCG, with no collective inside it;
+     *   2 = split by points: a rank keeps only the blocks its own points produce (S = sum over the
+     *       ranks of S_k; the diagonal blocks, 63 doubles per camera with the right-hand side, are
+     *       still summed, and every rank holds 1/nranks of them), the product q = S p of every PCG
+     *       iteration is summed over the ranks (6 doubles per camera), and the coarse matrix of
+     *       the two-level preconditioner is summed once per set-up.  Launch-per-iteration PCG only;
+     *       no dense fall-back.  Same iterates as the replicated form up to rounding;
+     *   0 = choose: replicated (the split form has only run in the in-process group on one GPU; it
+     *       pays where the 36 doubles per block of the replicated form cost more than a collective
+     *       per PCG iteration, and its product shrinks only as far as a rank's points touch fewer
+     *       cameras than all points do).
+     * Ignored with nranks <= 1, with the matrix-free product and with the dense solver. */
+    int32_t matrix_split;
 } sfmba_options;
 
 /* Camera models.  D = tangent numbers per camera (width of a Jacobian block and of every

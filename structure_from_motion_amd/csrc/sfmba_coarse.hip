@@ -346,7 +346,10 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
 // Builds Z, E = Z'SZ and its inverse; returns the buffer that holds D^-1 E^-1 D^-1 (k.scale = D).
 // `assembled`, when given, is recorded once nothing of the problem (cameras, UG, the matrix) is
 // read any more: what follows works on the coarse matrices alone.
-const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled) {
+// `sum_over_ranks`, when given, is called on E once it is assembled (on `st`): with the reduced matrix
+// split over the ranks E = Z'SZ is the sum of the ranks' Z'S_k Z.
+const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled,
+                                  void (*sum_over_ranks)(void*, double*, size_t), void* ctx) {
     const dim3 blk(kBlock);
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_basis<Bal>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
     else hipLaunchKernelGGL((k_coarse_basis<Pinhole>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
@@ -355,6 +358,7 @@ const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st,
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_assemble<Bal::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);
     else hipLaunchKernelGGL((k_coarse_assemble<Pinhole::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);
     hipLaunchKernelGGL(k_coarse_collect, dim3(cdiv(k.n_cpairs * kVecs * kVecs, kBlock)), blk, 0, st, k, k.E[0]);
+    if (sum_over_ranks) sum_over_ranks(ctx, k.E[0], total);
     if (assembled) (void)hipEventRecord(assembled, st);
     hipLaunchKernelGGL(k_coarse_scale, dim3((unsigned)((total + kBlock - 1) / kBlock)), blk, 0, st, k, k.E[0], k.E[1]);
     int src = 1;

@@ -204,6 +204,8 @@ struct HandleData {
     bool dense_flow = false;     // the single-launch factorisation is used (small systems)
     DBuf<int> dense_fail;
     int dense_fallbacks = 0;
+    bool split = false;           // partitioned solve with the reduced matrix split by points (options.matrix_split)
+    DBuf<double> dsum;            // its per-camera collective: diagonal blocks | T_c and right-hand-side part
     int cur = 0;                           // index of the current parameter buffers
     Dev dev{};
 

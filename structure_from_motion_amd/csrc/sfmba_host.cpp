@@ -281,6 +281,13 @@ void allreduce(H* h, double* buf, size_t count) {
     if (r != ncclSuccess) fail(SFMBA_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
 }
 
+// The coarse matrix of a split reduced matrix is the ranks' sum (launch_coarse_setup calls this).
+void sum_coarse_over_ranks(void* ctx, double* E, size_t n) { allreduce(static_cast<H*>(ctx), E, n); }
+const double* coarse_setup_here(H* h) {
+    const bool split = h->split && h->has_comm();
+    return launch_coarse_setup(h->dev, h->coarse, h->stream, nullptr, split ? sum_coarse_over_ranks : nullptr, h);
+}
+
 void read_scalars(H* h, double* out) {
     if (!h->has_comm()) {
         // every kernel that fills a slot has also written it to pinned host memory
@@ -417,10 +424,21 @@ void phase_damp(H* h, double lambda) {
             }
             launch_block_reduce(h->dev, h->stream);
         }
-        allreduce(h, h->Bsum.p, (size_t)h->n_ublk * h->cd * h->cd + (size_t)h->n_cam * h->cv);
+        if (h->split && h->has_comm()) {
+            // matrix split by points: the off-diagonal blocks stay this rank's own; what is summed
+            // over the ranks is per camera - the diagonal block and the camera-major sums
+            const size_t words = diag_collect_words(h->dev, h->cv);
+            h->dsum.alloc(words);
+            launch_diag_collect(h->dev, h->cv, tpart, h->dsum.p, h->stream);
+            allreduce(h, h->dsum.p, words);
+            launch_diag_spread(h->dev, h->cv, h->dsum.p, tpart, h->stream);
+        } else {
+            allreduce(h, h->Bsum.p, (size_t)h->n_ublk * h->cd * h->cd + (size_t)h->n_cam * h->cv);
+        }
         {
             Scope t(h, F_SCHUR);
-            launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream);
+            launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream,
+                                h->split && h->has_comm() ? 1.0 / h->opt.nranks : 1.0);
             h->fused_armed = h->fused_pcg;
         }
         h->coarse_valid = false;
@@ -540,7 +558,7 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         h->coarse.Einv = h->fused_einv;
     } else if (two_level && !h->coarse_valid) {
         Scope t(h, F_SCHUR);
-        h->coarse.Einv = launch_coarse_setup(h->dev, h->coarse, h->stream);
+        h->coarse.Einv = coarse_setup_here(h);
         h->coarse_valid = true;
     }
     {
@@ -556,7 +574,17 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
     auto queue_batch = [&](int slot) {
         for (int i = 0; i < batch; ++i) {
             int n_pq;
-            if (h->explicit_schur) {
+            if (h->explicit_schur && h->split && h->has_comm()) {
+                // this rank's share of q = S p; the ranks' sum; p'q from the complete product
+                {
+                    Scope t(h, F_BSR);
+                    launch_pcg_spmv_bsr(h->dev, cur, h->stream);
+                }
+                allreduce(h, h->pq.p, (size_t)h->n_cam * h->cd);
+                Scope t(h, F_PCGVEC);
+                launch_pcg_dot(h->dev, cur, h->stream);
+                n_pq = pcg_update_blocks(h->dev);
+            } else if (h->explicit_schur) {
                 Scope t(h, F_BSR);
                 launch_pcg_spmv_bsr(h->dev, cur, h->stream);
                 n_pq = pcg_spmv_blocks(h->dev);
@@ -1170,11 +1198,18 @@ SchurPlan sfmba::plan_schur(H* h) {
     int auto_dense_dim = 288;          // up to 48 six-number cameras: nine block rows of the single-launch factorisation
     if (const char* e = getenv("SFMBA_DENSE_AUTO_DIM")) auto_dense_dim = atoi(e);
     h->dense_auto = lin == SFMBA_SOLVER_AUTO && mode != 1 && dense_padded((int)std::min<int64_t>(n_red, 1 << 20)) <= auto_dense_dim;
-    const bool want_dense = lin == SFMBA_SOLVER_DENSE || h->dense_auto;
     h->dense_allowed = lin == SFMBA_SOLVER_AUTO && n_red <= dense_max;
     if (n_red > 16384 && lin == SFMBA_SOLVER_DENSE)
         fail(SFMBA_ERR_INVALID_ARGUMENT, "dense solver: reduced system of %lld unknowns is too large", (long long)n_red);
     h->use_dense = false;
+    // A partitioned solve keeps the reduced matrix replicated (all upper blocks summed over the
+    // ranks, PCG the same on every rank) or split by points (every rank the blocks of its own
+    // points, the product summed over the ranks per PCG iteration): options.matrix_split.
+    int split = h->opt.matrix_split;
+    if (const char* e = getenv("SFMBA_MATRIX_SPLIT")) split = atoi(e);
+    h->split = h->opt.nranks > 1 && mode != 1 && lin != SFMBA_SOLVER_DENSE && split == 2;
+    if (h->split) { h->dense_auto = false; h->dense_allowed = false; }
+    const bool want_dense = lin == SFMBA_SOLVER_DENSE || h->dense_auto;
     if (want_dense) mode = 2;          // the dense matrix is filled from the explicit blocks
     h->explicit_schur = false;
     h->n_ublk = h->n_pchunks = h->nnzb = 0;
@@ -1224,7 +1259,7 @@ void build_schur_structure(H* h, int64_t n_obs_all, const int64_t* cam_idx, cons
     // distinct camera pairs over all points of all ranks
     KeySet keys;
     auto key_of = [](int r, int c) { return ((uint64_t)(uint32_t)r << 32) | (uint32_t)c; };
-    if (h->n_obs == h->n_obs_all) {
+    if (h->n_obs == h->n_obs_all || h->split) {      // (split by points: the blocks of this rank's own points)
         for (int p = 0; p < np; ++p)
             for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; ++a)
                 for (int b = a + 1; b < pt_ptr[p + 1]; ++b) {
@@ -1408,6 +1443,7 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     int coarse = h->opt.pcg_coarse;
     if (const char* e = getenv("SFMBA_PCG_COARSE")) coarse = atoi(e);
     if (coarse > 0) pcg_mode = 1;           // the coarse space belongs to the launch-per-iteration solver
+    if (h->split) pcg_mode = 1;             // so does the matrix split over the ranks (a collective per iteration)
     h->fused_pcg = false;
     if (pcg_mode != 1 && !want_dense) {
         const int cap = pcg_fused_max_blocks(h->device);
@@ -1560,7 +1596,8 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         h->coarse_forced = coarse > 0;
         // left to choose, the operator comes from an earlier solve's matrix and is set up beside the
         // next linearisation instead of in front of the solve that uses it
-        h->coarse_async = coarse == 0;
+        // (split matrix: the set-up contains a collective and stays on the main stream)
+        h->coarse_async = coarse == 0 && !h->split;
         if (const char* e = getenv("SFMBA_COARSE_ASYNC")) h->coarse_async = h->coarse_async && atoi(e) != 0;
         // (its set-up costs the solves nothing, so it is switched on earlier than one set up in
         // front of every solve: measured at 0.2, 0.5 and 1 x the Final shape)
@@ -1981,6 +2018,7 @@ void sfmba_default_options(sfmba_options* o) {
     o->camera_model = SFMBA_CAMERA_PINHOLE;
     o->pcg_coarse = 0;
     o->setup_mode = 0;
+    o->matrix_split = 0;
 }
 
 int sfmba_create(const sfmba_options* opts, sfmba_handle** out) {
@@ -2296,6 +2334,7 @@ int sfmba_schur_matvec(sfmba_handle* h, const double* x, double* y) {
         HIP_TRY(hipMemcpyAsync(h->pz.p, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (h->explicit_schur) {
             launch_bsr_spmv(h->dev, h->pz.p, h->pq.p, h->stream);
+            if (h->split && h->has_comm()) allreduce(h, h->pq.p, n);     // this rank's share of S x
         } else {
             schur_product(h, h->pz.p, nullptr);
             launch_schur_apply(h->dev, h->pz.p, h->lin_lambda, h->pq.p, h->stream);
@@ -2327,7 +2366,7 @@ int sfmba_precondition(sfmba_handle* h, const double* r, double* z, int32_t* coa
         const bool two_level = h->explicit_schur && h->coarse_built;
         if (two_level) {
             if (!h->coarse_valid) {
-                h->coarse.Einv = launch_coarse_setup(h->dev, h->coarse, h->stream);
+                h->coarse.Einv = coarse_setup_here(h);
                 h->coarse_valid = true;
             }
             launch_coarse_apply(h->dev, h->coarse, 0, h->stream);

@@ -222,6 +222,7 @@ void launch_pcg_init(const Dev& d, double tol, int max_iter, hipStream_t st, dou
 void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st);            // explicit mode
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);                 // implicit mode: direction only
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);    // implicit mode: q = U* p - qS
+void launch_pcg_dot(const Dev& d, int cur, hipStream_t st);
 void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
 // whole PCG solve in one launch (explicit mode); returns the launch error
 int pcg_fused_max_blocks(int device);
@@ -247,11 +248,15 @@ void launch_schur_pairs(const Dev& d, hipStream_t st);
 void launch_pchunk_records(const Dev& d, int4* rec, hipStream_t st);
 void launch_block_reduce(const Dev& d, hipStream_t st);
 // full matrix, preconditioner, right-hand side; with `scaled` also F, bhat, Shat of the single-launch PCG
-void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st);
+void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st, double share = 1.0);
+size_t diag_collect_words(const Dev& d, int nv);
+void launch_diag_collect(const Dev& d, int nv, const double* tpart, double* out, hipStream_t st);
+void launch_diag_spread(const Dev& d, int nv, const double* in, double* tpart, hipStream_t st);
 void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_coarse.hip
-const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled = nullptr);    // returns the buffer holding the inverse
+const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled = nullptr,
+                                  void (*sum_over_ranks)(void*, double*, size_t) = nullptr, void* ctx = nullptr);    // returns the buffer holding the inverse
 void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st);  // pz += Z E^-1 Z' pr, r'z partials
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)
 void launch_triangulate(const double* P1, const double* P2, int n, const double2* x1, const double2* x2,

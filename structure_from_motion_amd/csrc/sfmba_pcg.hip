@@ -251,6 +251,25 @@ __global__ __launch_bounds__(kBlock) void k_pcg_q(Dev d, double lambda, int cur)
     if (threadIdx.x == 0) d.dot_part[blockIdx.x] = s;
 }
 
+// p'q partials of the direction and a product that was completed after the product kernel (the
+// matrix split over the ranks: q is the ranks' sum); thread = (camera, row) as in k_pcg_update,
+// which adds these partials up.
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_pcg_dot(Dev d, int cur) {
+    constexpr int kCams = cams_per_update_block<ND>();
+    __shared__ double red[16];
+    if (d.pcg[cur ^ 1].done) return;
+    const int local = threadIdx.x / ND, k = threadIdx.x - ND * local;
+    const int c = blockIdx.x * kCams + local;
+    double dot = 0.0;
+    if (local < kCams && c < d.n_cam) {
+        const size_t o = ND * (size_t)c + k;
+        dot = d.pp[cur ^ 1][o] * d.pq[o];
+    }
+    const double s = block_sum(dot, red);
+    if (threadIdx.x == 0) d.dot_part[blockIdx.x] = s;
+}
+
 // alpha = rz / p'q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; r'z partials.  thread = (camera, row).
 template <int ND>
 __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_parts) {
@@ -1535,6 +1554,10 @@ void launch_pcg_dir(const Dev& d, int cur, hipStream_t st) {
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st) {
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_q<Bal::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
     else hipLaunchKernelGGL((k_pcg_q<Pinhole::ND>), dim3(blocks_cam(d)), dim3(kBlock), 0, st, d, lambda, cur);
+}
+void launch_pcg_dot(const Dev& d, int cur, hipStream_t st) {
+    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_dot<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur);
+    else hipLaunchKernelGGL((k_pcg_dot<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur);
 }
 void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st) {
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_update<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);

@@ -172,6 +172,9 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d, int nn) {
 }
 
 // Finishing passes over the (all-ranks) upper sums B: S_rc = -B, S_cr = -B', S_cc = U*_c - B_cc.
+// With the matrix split by points over the ranks, B holds this rank's off-diagonal sums and the
+// all-ranks diagonal ones: the stored diagonal block is `share` = 1 / nranks of the true one, so
+// that the ranks' matrices add up to S, while the preconditioner block is the inverse of the true one.
 //
 // k_finish_diag, one thread per camera: the diagonal block of the full block-CSR matrix
 // (U*_c - T_c - B_cc with T_c from the camera-major pass k_sdiag_cm), its
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_block_reduce(Dev d, int nn) {
 // workgroups instead of 7; 22 -> 7 us per launch).
 constexpr int kDiagCams = 16;
 template <class M>
-__global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f) {
+__global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const double* __restrict__ tpart, FusedPcg f, double share) {
     constexpr int ND = M::ND, NU = M::NU, NV = M::NV, NN = ND * ND;
     if (f.F != nullptr) {
         // arm the exchange buffers of the single-launch PCG: every word all bits set
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const 
     for (int i = 0; i < ND; ++i) {
         dg[i] = S[i][i];
 #pragma unroll
-        for (int j = 0; j < ND; ++j) { So[ND * i + j] = S[i][j]; A[i][j] = 0.5 * (S[i][j] + S[j][i]); }
+        for (int j = 0; j < ND; ++j) { So[ND * i + j] = share * S[i][j]; A[i][j] = 0.5 * (S[i][j] + S[j][i]); }
     }
     const bool ok = spd_inverse(A, Ai, Li);
     if (!ok) {
@@ -379,16 +382,48 @@ void launch_block_reduce(const Dev& d, hipStream_t st) {
     if (d.n_ublk > 0)
         hipLaunchKernelGGL(k_block_reduce, dim3(cdiv(d.n_ublk * nn, kBlock)), dim3(kBlock), 0, st, d, nn);
 }
-void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st) {
+// The per-camera numbers a split matrix still sums over the ranks, in one buffer: the diagonal
+// blocks of B (scattered in Bsum) followed by the camera-major sums `tpart`.
+__global__ __launch_bounds__(kBlock) void k_diag_collect(Dev d, int nn, int nv, const double* __restrict__ tpart, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t nb = (size_t)d.n_cam * nn, nt = (size_t)d.n_cam * nv;
+    if (i < nb) {
+        const int c = (int)(i / nn), e = (int)(i - (size_t)nn * c);
+        out[i] = d.Bsum[(size_t)nn * d.ublk_diag[c] + e];
+    } else if (i < nb + nt) {
+        out[i] = tpart[i - nb];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_diag_spread(Dev d, int nn, int nv, const double* __restrict__ in, double* __restrict__ tpart) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t nb = (size_t)d.n_cam * nn, nt = (size_t)d.n_cam * nv;
+    if (i < nb) {
+        const int c = (int)(i / nn), e = (int)(i - (size_t)nn * c);
+        d.Bsum[(size_t)nn * d.ublk_diag[c] + e] = in[i];
+    } else if (i < nb + nt) {
+        tpart[i - nb] = in[i];
+    }
+}
+size_t diag_collect_words(const Dev& d, int nv) { return (size_t)d.n_cam * (cam_dim(d) * cam_dim(d) + nv); }
+void launch_diag_collect(const Dev& d, int nv, const double* tpart, double* out, hipStream_t st) {
+    const int nn = cam_dim(d) * cam_dim(d);
+    hipLaunchKernelGGL(k_diag_collect, dim3((unsigned)((diag_collect_words(d, nv) + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, d, nn, nv, tpart, out);
+}
+void launch_diag_spread(const Dev& d, int nv, const double* in, double* tpart, hipStream_t st) {
+    const int nn = cam_dim(d) * cam_dim(d);
+    hipLaunchKernelGGL(k_diag_spread, dim3((unsigned)((diag_collect_words(d, nv) + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, d, nn, nv, in, tpart);
+}
+
+void launch_schur_finish(const Dev& d, double lambda, const double* tpart, const FusedPcg* scaled, hipStream_t st, double share) {
     FusedPcg f{};
     if (scaled) f = *scaled;
     const int nn = cam_dim(d) * cam_dim(d);
     if (d.model == MODEL_BAL) {
-        hipLaunchKernelGGL((k_finish_diag<Bal>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f);
+        hipLaunchKernelGGL((k_finish_diag<Bal>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f, share);
         if (d.n_ublk > 0)
             hipLaunchKernelGGL((k_finish_offdiag<Bal::ND>), dim3(cdiv(d.n_ublk, kBlock / nn)), dim3(kBlock), 0, st, d, f);
     } else {
-        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f);
+        hipLaunchKernelGGL((k_finish_diag<Pinhole>), dim3(cdiv(d.n_cam, kDiagCams)), dim3(64), 0, st, d, lambda, tpart, f, share);
         if (d.n_ublk > 0)
             hipLaunchKernelGGL((k_finish_offdiag<Pinhole::ND>), dim3(cdiv(d.n_ublk, kBlock / nn)), dim3(kBlock), 0, st, d, f);
     }

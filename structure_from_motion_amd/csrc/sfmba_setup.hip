@@ -464,7 +464,7 @@ void device_setup(H* h, const int64_t* cam_idx, const int64_t* pt_idx) {
     B.reserve(2 * Arena::pad(8 * ((size_t)no + 2)) + 2 * Arena::pad(8 * ((size_t)N + 2)) + 16 * 256);
     long long* pcnt = B.get<long long>((size_t)no + 1);
     long long* poff = B.get<long long>((size_t)no + 1);
-    const bool others = no != N;                       // other ranks' points: only their camera pairs matter
+    const bool others = no != N && !h->split;          // other ranks' points: only their camera pairs matter (replicated matrix)
     long long* ocnt = B.get<long long>(others ? (size_t)N + 1 : 1);
     long long* ooff = B.get<long long>(others ? (size_t)N + 1 : 1);
     hipLaunchKernelGGL(k_pair_counts, dim3(grid_for((size_t)no + 1)), dim3(kT), 0, st, h->pt_ptr.p, h->pm_pt.p, h->pm_cam.p, no, 0, 0, pcnt);

@@ -62,7 +62,7 @@ class Options(C.Structure):
         ("dense_max_dim", C.c_int32), ("verbose", C.c_int32), ("profile", C.c_int32),
         ("device", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
         ("pcg_mode", C.c_int32), ("pcg_blocks", C.c_int32), ("camera_model", C.c_int32), ("pcg_coarse", C.c_int32),
-        ("setup_mode", C.c_int32),
+        ("setup_mode", C.c_int32), ("matrix_split", C.c_int32),
     ]
 
 

@@ -46,7 +46,20 @@ def _worker(rank, world, port, out_dir):
     sp = np.einsum("nij,nj->ni", Vinv, tp)
     q = np.zeros((9, 6)); np.add.at(q, m.ci, np.einsum("nij,nj->ni", W, sp[m.pi]))
     q = _allreduce(q)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U=U, gc=gc, cost=cost, q=q, lo=lo, hi=hi,
+    # the explicit matrix split by points: this rank's blocks B_k = W Vinv W' over its own points and
+    # 1 / world of the (all-reduced) camera blocks; the product is the ranks' sum, one all-reduce of
+    # 6 numbers per camera, and no block is ever exchanged
+    Wd = np.zeros((9 * 6, m.np_ * 3))
+    for n in range(m.no):
+        Wd[6 * m.ci[n]:6 * m.ci[n] + 6, 3 * m.pi[n]:3 * m.pi[n] + 3] += W[n]
+    Vd = np.zeros((m.np_ * 3, m.np_ * 3))
+    for k in range(m.np_):
+        Vd[3 * k:3 * k + 3, 3 * k:3 * k + 3] = Vinv[k]
+    share = -Wd @ Vd @ Wd.T
+    for c in range(9):
+        share[6 * c:6 * c + 6, 6 * c:6 * c + 6] += U[c] / world
+    qs = _allreduce((share @ x.ravel()).reshape(9, 6))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U=U, gc=gc, cost=cost, q=q, qs=qs, lo=lo, hi=hi,
              n_obs=m.no)
     dist.destroy_process_group()
 
@@ -80,4 +93,7 @@ def test_two_rank_allreduce_reproduces_the_global_system(tmp_path):
         assert np.abs(z["gc"] - gc).max() <= 1e-12 * np.abs(gc).max()
         assert abs(float(z["cost"]) - 0.5 * np.sum(r * r)) <= 1e-12 * 0.5 * np.sum(r * r)
         assert np.abs(z["q"] - q).max() <= 1e-12 * np.abs(q).max()
+        # split explicit matrix: the ranks' shares add up to S = U - W Vinv W'
+        Sx = np.einsum("cij,cj->ci", U, x) - q
+        assert np.abs(z["qs"] - Sx).max() <= 1e-11 * np.abs(Sx).max()
     assert np.array_equal(outs[0]["U"], outs[1]["U"])     # every rank holds the same reduced data

@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 SOLVERS = {"pcg-implicit": dict(linear_solver=1, schur_mode=1),
            "pcg-explicit": dict(linear_solver=1, schur_mode=2, pcg_mode=2),
            "pcg-explicit-stepwise": dict(linear_solver=1, schur_mode=2, pcg_mode=1),
-           "dense": dict(linear_solver=2)}
+           "dense": dict(linear_solver=2),
+           # the reduced matrix split by points: a rank keeps the blocks of its own points, the product of
+           # every PCG iteration is summed over the ranks
+           "pcg-explicit-split": dict(linear_solver=1, schur_mode=2, pcg_mode=1, matrix_split=2)}
 
 
 def solve_sharded(p, nranks, **opts):
@@ -72,10 +75,12 @@ def test_sharded_solve_matches_single_handle(solver, nranks):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
-def test_sharded_two_level_solve():
-    # several clusters; the coarse matrix is built from the all-reduced blocks on every rank
+@pytest.mark.parametrize("split", [1, 2])
+def test_sharded_two_level_solve(split):
+    # several clusters; the coarse matrix is built from the all-reduced blocks on every rank, or,
+    # with the matrix split by points, summed over the ranks from their own blocks
     p = syn.make_problem(300, 8000, 60000, seed=8)
-    opts = dict(linear_solver=1, schur_mode=2, pcg_coarse=64)
+    opts = dict(linear_solver=1, schur_mode=2, pcg_coarse=64, matrix_split=split)
     with E.Engine(**opts) as eng:
         eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"],
                         p["points_2d"], p["K"])
@@ -88,7 +93,7 @@ def test_sharded_two_level_solve():
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
-@pytest.mark.parametrize("solver", ["pcg-explicit", "pcg-explicit-stepwise", "pcg-implicit"])
+@pytest.mark.parametrize("solver", ["pcg-explicit", "pcg-explicit-stepwise", "pcg-implicit", "pcg-explicit-split"])
 def test_sharded_solve_with_rejected_steps(solver):
     # rejected steps re-damp without a new linearisation; with the explicit matrix that repeats the
     # camera-major pass and its collective on every rank
@@ -208,3 +213,66 @@ def test_sharded_solve_with_the_coarse_correction_inside_the_single_launch():
         assert abs(st["final_cost"] - ref.final_cost) <= 1e-9 * ref.final_cost
         assert np.abs(pts - ref_pts).max() <= 1e-6
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("by_camera", [False, True])
+def test_split_matrix_product_and_traffic(by_camera):
+    """With the matrix split by points the ranks' shares add up to the reduced matrix (the product
+    through the diagnostic entry point equals the single-handle one) and a rank hands the collectives
+    fewer numbers per LM iteration than with the replicated matrix."""
+    p = syn.make_problem(60, 1500, 9000, seed=3, window=6)
+    if by_camera:
+        # points numbered by their smallest observing camera: a rank's range of points then sees a
+        # range of cameras, and its share of the matrix is a band of block rows
+        ci, pi = p["camera_indices"], p["point_indices"]
+        first = np.full(p["n_points"], p["n_cameras"]); np.minimum.at(first, pi, ci)
+        order = np.argsort(first, kind="stable")
+        new_of = np.empty_like(order); new_of[order] = np.arange(order.size)
+        p = dict(p, points_3d=p["points_3d"][order], point_indices=new_of[pi])
+    args = (p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
+    x = np.random.default_rng(0).standard_normal(60 * 6)
+    with E.Engine(linear_solver=1, schur_mode=2, pcg_mode=1) as eng:
+        eng.set_problem(*args)
+        eng.linearize(1e-4)
+        want = eng.schur_matvec(x)
+        n_blocks = eng.solve().schur_blocks
+    group = E.local_group_create(2)
+    got, blocks, err = [None, None], [None, None], []
+
+    def work(r):
+        try:
+            with E.Engine(rank=r, nranks=2, linear_solver=1, schur_mode=2, matrix_split=2) as eng:
+                eng.set_problem(*args)
+                eng.comm_init_local(group)
+                eng.linearize(1e-4)
+                got[r] = eng.schur_matvec(x)
+                blocks[r] = eng.solve().schur_blocks
+        except Exception as e:      # pragma: no cover - reported below
+            err.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is still running"
+    E.local_group_destroy(group)
+    assert not err, err
+    for r in range(2):
+        assert np.abs(got[r] - want).max() <= 1e-10 * np.abs(want).max()
+    # a rank holds only the blocks its own points touch (plus every diagonal): never more than all of
+    # them, and all of them when, as here, the points of a rank are spread over the whole ring
+    assert all(b <= n_blocks for b in blocks) and sum(blocks) >= n_blocks
+    if by_camera:
+        assert all(b < 0.75 * n_blocks for b in blocks)
+
+
+def test_split_matrix_with_the_host_set_up_path():
+    """Both set-up paths build the same structure for a rank of a split matrix: bit-identical solves."""
+    g = load_golden("shuffled_9_200_700")
+    opts = SOLVERS["pcg-explicit-split"]
+    dev = solve_sharded(g, 2, **opts)
+    host = solve_sharded(g, 2, setup_mode=1, **opts)
+    for a, b in zip(dev, host):
+        assert a[0]["final_cost"] == b[0]["final_cost"] and a[0]["iterations"] == b[0]["iterations"]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
