@@ -213,6 +213,10 @@ def main():
         p["K"] = None
     else:
         p = syn.make_shape(args.shape, seed=args.seed, scale=args.scale)
+    if world > 1 and args.matrix_split == 2:
+        # (a rank's share of a split matrix is a band of block rows when the points follow the cameras)
+        from structure_from_motion_amd.distributed import number_points_by_camera
+        p, _ = number_points_by_camera(p)
     solver_opts = dict(linear_solver=args.linear_solver, schur_mode=args.schur_mode, pcg_mode=args.pcg_mode, pcg_coarse=args.pcg_coarse,
                        camera_model=args.camera_model, matrix_split=args.matrix_split)
     eng = Engine(device=local_rank, rank=rank, nranks=world, **solver_opts)

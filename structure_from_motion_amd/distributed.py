@@ -31,6 +31,29 @@ def point_partition(point_indices, n_points, rank, nranks):
     return lo, hi
 
 
+def number_points_by_camera(prob):
+    """The same problem with its points numbered by their smallest observing camera (stable, so
+    points of one camera keep their order); also returns `order`, the old number of every new point
+    (``points_3d_old[order] = points_3d_new``).  A solve does not depend on the numbering, but a
+    rank's contiguous range of points then sees a range of cameras: with the reduced matrix split
+    by points (options.matrix_split = 2) its share of the matrix is a band of block rows instead of
+    the full pattern."""
+    ci = np.asarray(prob["camera_indices"], dtype=np.int64)
+    pi = np.asarray(prob["point_indices"], dtype=np.int64)
+    n_points = len(prob["points_3d"])
+    first = np.full(n_points, np.iinfo(np.int64).max)
+    np.minimum.at(first, pi, ci)
+    order = np.argsort(first, kind="stable")
+    new_of = np.empty_like(order)
+    new_of[order] = np.arange(n_points)
+    out = dict(prob)
+    out["points_3d"] = np.asarray(prob["points_3d"])[order]
+    out["point_indices"] = new_of[pi]
+    if "true_points_3d" in prob:
+        out["true_points_3d"] = np.asarray(prob["true_points_3d"])[order]
+    return out, order
+
+
 def shard_problem(prob, lo, hi):
     """The sub-problem of points [lo, hi): all cameras, the owned points and their observations
     (point indices re-based to the shard)."""

@@ -97,3 +97,19 @@ def test_two_rank_allreduce_reproduces_the_global_system(tmp_path):
         Sx = np.einsum("cij,cj->ci", U, x) - q
         assert np.abs(z["qs"] - Sx).max() <= 1e-11 * np.abs(Sx).max()
     assert np.array_equal(outs[0]["U"], outs[1]["U"])     # every rank holds the same reduced data
+
+
+def test_numbering_points_by_camera_keeps_the_problem_and_bands_the_ranks():
+    p = syn.make_problem(60, 1500, 9000, seed=3, window=6)
+    q, order = sd.number_points_by_camera(p)
+    assert sorted(order.tolist()) == list(range(1500))
+    assert np.array_equal(q["points_3d"], p["points_3d"][order])
+    # every observation still names the same camera and the same point coordinates
+    assert np.array_equal(q["camera_indices"], p["camera_indices"])
+    assert np.array_equal(q["points_3d"][q["point_indices"]], p["points_3d"][p["point_indices"]])
+    seen = []
+    for prob in (p, q):
+        lo, hi = sd.point_partition(prob["point_indices"], 1500, 0, 2)
+        mine = (prob["point_indices"] >= lo) & (prob["point_indices"] < hi)
+        seen.append(len(np.unique(prob["camera_indices"][mine])))
+    assert seen[0] == 60 and seen[1] < 45        # a range of points now sees a range of cameras

@@ -224,11 +224,8 @@ def test_split_matrix_product_and_traffic(by_camera):
     if by_camera:
         # points numbered by their smallest observing camera: a rank's range of points then sees a
         # range of cameras, and its share of the matrix is a band of block rows
-        ci, pi = p["camera_indices"], p["point_indices"]
-        first = np.full(p["n_points"], p["n_cameras"]); np.minimum.at(first, pi, ci)
-        order = np.argsort(first, kind="stable")
-        new_of = np.empty_like(order); new_of[order] = np.arange(order.size)
-        p = dict(p, points_3d=p["points_3d"][order], point_indices=new_of[pi])
+        from structure_from_motion_amd.distributed import number_points_by_camera
+        p, _ = number_points_by_camera(p)
     args = (p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
     x = np.random.default_rng(0).standard_normal(60 * 6)
     with E.Engine(linear_solver=1, schur_mode=2, pcg_mode=1) as eng:
