@@ -317,6 +317,20 @@ def test_small_camera_systems_are_factored_and_start_undamped():
     assert chain.iterations == st.iterations and abs(chain.final_cost - st.final_cost) <= 1e-9 * st.final_cost
 
 
+@pytest.mark.parametrize("n_cam", [2, 3, 5, 6, 11, 16, 17, 33, 47, 48])
+def test_factored_systems_of_every_size(n_cam):
+    """The single-launch factorisation on systems of one to nine block rows, full and ragged last
+    rows alike (6 n_cam is a multiple of 32 only at 16 and 48 cameras): SciPy's cost or better at
+    the reference's tolerances, in no more iterations than SciPy has evaluations plus two."""
+    p = syn.make_problem(n_cam, 60 * n_cam, 240 * n_cam if n_cam > 3 else 120 * n_cam, seed=100 + n_cam, window=min(6, n_cam))
+    ref = o.solve_reference(p)
+    with make_engine(p) as eng:
+        st = eng.solve()
+    assert st.linear_solver == 2 and st.pcg_iterations == 0 and st.status > 0
+    assert st.final_cost <= ref["cost"] * (1 + 1e-6)
+    assert st.iterations <= ref["nfev"] + 2
+
+
 @pytest.mark.parametrize("kind", [1, 2])
 def test_recoveries_of_the_single_launch_factorisation(kind, monkeypatch):
     """What the LM loop does when the single-launch factorisation reports a matrix that is not
