@@ -205,6 +205,7 @@ struct HandleData {
     DBuf<int> dense_fail;
     int dense_fallbacks = 0;
     bool split = false;           // partitioned solve with the reduced matrix split by points (options.matrix_split)
+    DBuf<double> czhat;           // F^-T Z of every camera for the single-launch PCG with 9 x 9 blocks
     DBuf<double> dsum;            // its per-camera collective: diagonal blocks | T_c and right-hand-side part
     int cur = 0;                           // index of the current parameter buffers
     Dev dev{};

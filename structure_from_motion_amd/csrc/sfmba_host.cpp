@@ -344,6 +344,7 @@ void arm_fused_coarse(H* h, FusedPcg& f) {
     f.c_n = h->coarse.n; f.c_npad = h->coarse.n_pad;
     f.cam_cl = h->coarse.cam_cl; f.cl_ptr = h->coarse.cl_ptr;
     f.c_z = h->coarse.Z; f.c_einv = h->fused_einv; f.c_scale = h->coarse.scale;
+    f.c_zhat = h->cd != 6 ? h->czhat.p : nullptr;
     f.wg_cl = h->wg_cl.p;
 }
 
@@ -835,7 +836,10 @@ void do_solve(H* h, sfmba_stats* out) {
     // correction at hand; block-Jacobi PCG alone pays for every cut with more iterations (measured with
     // the 9-number camera at the Venice shape: twice the PCG iterations, no outer iteration saved)
     const bool low_damping_ok = h->use_dense || (h->explicit_schur && (h->fused_pcg ? h->fused_coarse_ok : h->coarse_built));
-    double lm_down = low_damping_ok ? 1.0 / 30.0 : 1.0 / 3.0;
+    // (the camera with its own intrinsics is the less linear model: a tenth there - on starts ten times
+    // as far off as usual the thirtyfold cut took 13 iterations and stopped 3e-4 above the converged
+    // cost, the tenfold one 6 iterations to within 1e-6, and both take 3 on ordinary starts)
+    double lm_down = low_damping_ok ? (h->model == MODEL_BAL ? 1.0 / 10.0 : 1.0 / 30.0) : 1.0 / 3.0;
     if (const char* e = getenv("SFMBA_LM_DOWN")) lm_down = atof(e);
     double gain_fraction = 0.05;             // of ftol x cost, per PCG iteration (tuning: SFMBA_PCG_GAIN, negative = rule off)
     if (const char* e = getenv("SFMBA_PCG_GAIN")) gain_fraction = atof(e);
@@ -1502,6 +1506,8 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     // kernels' limit does not hold: clusters go down to the eight camera rows of one of its
     // workgroups, as many of them as its 288 coarse unknowns admit (about 36).  A chain of 47 views
     // then gets 5 clusters instead of none.
+    // (6 x 6 blocks only: with 9 x 9 blocks a launch with the correction costs more, and at 49 cameras
+    // it was measured slower than block-Jacobi alone, 0.68 against 0.54 ms)
     const bool fused_small = coarse == 0 && h->fused_pcg && h->cd == 6 && h->fused.pipelined && n_cam < 36 * 48;
     if (fused_small) {
         // the smallest size, from the eight rows of a workgroup up, with which the columns of every
@@ -1604,11 +1610,11 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         if (h->coarse_async) h->coarse_from = 12;
         if (h->fused_pcg) {
             // the same space inside the single launch (k_pcg_pipe2), where its limits hold:
-            // 6 x 6 blocks, the pipelined form, at most 256 workgroups of 8 rows, clusters of at
+            // the pipelined form, at most 256 workgroups of 8 rows, clusters of at
             // least 8 cameras spread over at most 7 workgroups, at most 288 coarse unknowns after
             // padding, at most 4 clusters among the columns of the rows of one workgroup
             const int rows = pcg_fused_rows_per_block();
-            bool ok = h->cd == 6 && h->fused.pipelined && h->fused_blocks <= 256 && k7.n_pad <= 288 && k >= rows;
+            bool ok = (h->cd == 6 || h->cd == 9) && h->fused.pipelined && h->fused_blocks <= 256 && k7.n_pad <= 288 && k >= rows;
             for (int i = 0; ok && i < n_cl; ++i) ok = (cl_ptr[i + 1] - 1) / rows - cl_ptr[i] / rows + 1 <= 7;
             std::vector<int> wg_cl((size_t)5 * std::max(h->fused_blocks, 1), 0);
             for (int b = 0; ok && b * rows < n_cam && b < h->fused_blocks; ++b) {
@@ -1626,6 +1632,7 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
             if (ok) {
                 h->wg_cl.upload(wg_cl, st);
                 HIP_TRY(hipStreamSynchronize(st));
+                if (h->cd != 6) h->czhat.alloc((size_t)n_cam * kCoarseVecs * h->cd);
             }
             if (const char* e = getenv("SFMBA_PCG_FUSED_COARSE")) ok = ok && atoi(e) != 0;
             h->fused_coarse_ok = ok;

@@ -85,7 +85,8 @@ struct FusedPcg {
     const int* cam_cl;        // [n_cam] cluster of each camera
     const int* cl_ptr;        // [clusters + 1] camera range of each cluster
     const int* wg_cl;         // [blocks][5] per workgroup: count, then the clusters among the columns of its rows
-    const double* c_z;        // [n_cam][7][6] coarse basis
+    const double* c_z;        // [n_cam][7][nd] coarse basis
+    const double* c_zhat;     // [n_cam][7][nd] work array: F^-T Z of every camera (9 x 9 blocks), or null
     const double* c_einv;     // [c_npad][c_npad] (D E D)^-1
     const double* c_scale;    // [c_npad] D
 };

@@ -1071,8 +1071,16 @@ constexpr int kC2Cols = 18;             // columns of C per thread: n_pad <= 16 
 constexpr int kC2MaxBlocks = 256;
 constexpr int kC2Span = 7;              // workgroups with rows in one cluster, at most
 
+// A value every lane holds alike, moved to scalar registers (where vector registers are short).
+__device__ __forceinline__ double to_scalar(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int ND>
 __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
-    constexpr int ND = 6, NV = kCoarseVecs;
+    constexpr int NV = kCoarseVecs, NN = ND * ND;
     __shared__ double red[kFusedWaves][kC2Rec];
     __shared__ double2 dotbuf[kFusedWaves];
     __shared__ __attribute__((aligned(16))) double tiles[kFusedWaves][64 * ND + 64];
@@ -1084,7 +1092,16 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     __shared__ double crows[kC2WgCl * NV][16 * kC2Cols + 4];     // (the 4: rows start 8 banks apart)
     __shared__ int off_lds[kFusedWaves][ND][64];
     __shared__ int fail_lds;
+    // With 9 x 9 blocks the registers are full: the five vectors only the owning lanes update
+    // (z, q, s, p, x) then live in LDS, and the gather keeps three loads in flight instead of ND.
+    constexpr bool kLean = ND > 6;
+    __shared__ double own_lds[kLean ? kFusedWaves * 5 * 16 : 1];
+    __shared__ int tb_lds[kLean ? kFusedThreads : 1];           // per thread: first workgroup | span << 8 | second-cluster bits << 12
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* own = own_lds + (kLean ? (tid >> 6) * 5 * 16 : 0);
+    if constexpr (kLean) {
+        if (lane < 16) { own[lane] = 0.0; own[16 + lane] = 0.0; own[32 + lane] = 0.0; own[48 + lane] = 0.0; own[64 + lane] = 0.0; }
+    }
     const int G = gridDim.x, row = blockIdx.x * kFusedWaves + w;
     const bool mine = row < a.n_cam;
     const long long t_start = (long long)wall_clock64();
@@ -1100,9 +1117,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     // this lane's block of the row, the word offsets of the cooperative gather, the cluster of
     // the block's column
     int nb = 0, b0 = 0;
-    double S[36];
+    double S[NN];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) S[i] = 0.0;
+    for (int i = 0; i < NN; ++i) S[i] = 0.0;
 #pragma unroll
     for (int t = 0; t < ND; ++t) off_lds[w][t][lane] = -1;
     int cl = -1;
@@ -1115,9 +1132,16 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
             off_lds[w][t][lane] = blk < nb ? a.bsr_col[b0 + blk] * ND + j : -1;
         }
         if (lane < nb) {
-            const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)(b0 + lane));
+            if constexpr (ND == 6) {
+                const double2* sp = reinterpret_cast<const double2*>(a.Shat + 36 * (size_t)(b0 + lane));
 #pragma unroll
-            for (int i = 0; i < 18; ++i) { const double2 v = sp[i]; S[2 * i] = v.x; S[2 * i + 1] = v.y; }
+                for (int i = 0; i < 18; ++i) { const double2 v = sp[i]; S[2 * i] = v.x; S[2 * i + 1] = v.y; }
+            } else {
+                // (blocks of an odd size start on 8-byte boundaries only)
+                const double* sp = a.Shat + NN * (size_t)(b0 + lane);
+#pragma unroll
+                for (int i = 0; i < NN; ++i) S[i] = sp[i];
+            }
             cl = a.cam_cl[a.bsr_col[b0 + lane]];
         }
     }
@@ -1127,9 +1151,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     const bool is_new = lane < nb && (lane == 0 || cl != cl_prev);
     const unsigned long long new_mask = __ballot(is_new);
     const int slot = __popcll(new_mask & ((2ull << lane) - 1ull)) - 1;
-    const int n_rowcl = __popcll(new_mask);
+    const int n_rowcl = __builtin_amdgcn_readfirstlane(__popcll(new_mask));
     // the clusters among the columns of this workgroup's rows: listed by the host (count, then ids)
-    const int wgcl_n = a.wg_cl[(kC2WgCl + 1) * blockIdx.x];
+    const int wgcl_n = __builtin_amdgcn_readfirstlane(a.wg_cl[(kC2WgCl + 1) * blockIdx.x]);
     int wgcl[kC2WgCl];
 #pragma unroll
     for (int e = 0; e < kC2WgCl; ++e) wgcl[e] = a.wg_cl[(kC2WgCl + 1) * blockIdx.x + 1 + e];
@@ -1168,6 +1192,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
             if (a.cam_cl[b * kFusedWaves] != I) tsecond |= 1u << (b - tb0);
         tb1 = min(tb1, tb0 + kC2Span - 1);      // (the host admits no longer range)
     }
+    if constexpr (kLean) tb_lds[tid] = tb1 >= tb0 ? (tb0 | ((tb1 - tb0 + 1) << 8) | ((int)tsecond << 12)) : 0;
 
     // Zhat of this row: lane j < 7 solves F_r' x = Z_r[j] (F lower triangular, so F' x = z is a back
     // substitution) and keeps column j; lane k < 6 keeps row k
@@ -1181,8 +1206,19 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         }
     };
     if (lane < NV) {
-        double zc[ND] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (!flag && mine) back_subst(a.F + 36 * (size_t)row, a.c_z + (NV * (size_t)row + lane) * ND, zc);
+        double zc[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) zc[k] = 0.0;
+        if (!flag && mine) {
+            if constexpr (ND == 6) {
+                back_subst(a.F + NN * (size_t)row, a.c_z + (NV * (size_t)row + lane) * ND, zc);
+            } else {
+                // (larger blocks: Zhat of every camera was formed by k_coarse_zhat in front of this launch)
+                const double* __restrict__ zh = a.c_zhat + (NV * (size_t)row + lane) * ND;
+#pragma unroll
+                for (int k = 0; k < ND; ++k) zc[k] = zh[k];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < ND; ++k) zhat[w][k][lane] = zc[k];
     }
@@ -1194,6 +1230,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
 #pragma unroll
         for (int e = 0; e < kC2WgCl; ++e) if (e < wgcl_n && wgcl[e] == J) own_ws = e;
     }
+    own_ws = __builtin_amdgcn_readfirstlane(own_ws);
 
     double o_r = 0.0, o_u = 0.0, o_w = 0.0, o_z = 0.0, o_q = 0.0, o_s = 0.0, o_p = 0.0, o_x = 0.0;
 
@@ -1252,6 +1289,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
             const unsigned long long* base = drec + kC2Rec * (size_t)(gen % kSlots) * G;
             const bool reader = tid < G;
             const int tj = 2 + tid % NV;
+            if constexpr (kLean) {
+                const int info = tb_lds[tid];
+                tb0 = info & 255; tb1 = tb0 + ((info >> 8) & 15) - 1; tsecond = (unsigned)(info >> 12);
+            }
             for (int spins = 1;; ++spins) {
                 bool ok = true;
                 if (reader) {
@@ -1284,6 +1325,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         gam = 0.0; del = 0.0;
 #pragma unroll
         for (int i = 0; i < kFusedWaves; ++i) { const double2 d2 = dotbuf[i]; gam += d2.x; del += d2.y; }
+        if constexpr (kLean) { gam = to_scalar(gam); del = to_scalar(del); }
         if (NV * wgcl_n > 4 * w) {          // this wavefront has rows of the list (four per wavefront)
             double part = 0.0;
             if (c_act) {
@@ -1323,18 +1365,27 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     if (!flag) {
         // generation 0: r0 = bhat, u0 = Mhat^-1 r0 needs the coarse sums of bhat; w0 = Shat u0 =
         // Shat bhat + G y (bhat of the row's columns is in memory)
-        double y[ND] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double y[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) y[i] = 0.0;
         if (mine && lane < nb) {
-            const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b0 + lane]);
-            const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
-            const double rc[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+            double rc[ND];
+            if constexpr (ND == 6) {
+                const double2* rv = reinterpret_cast<const double2*>(a.bhat + 6 * (size_t)a.bsr_col[b0 + lane]);
+                const double2 r0 = rv[0], r1 = rv[1], r2 = rv[2];
+                rc[0] = r0.x; rc[1] = r0.y; rc[2] = r1.x; rc[3] = r1.y; rc[4] = r2.x; rc[5] = r2.y;
+            } else {
+                const double* rv = a.bhat + ND * (size_t)a.bsr_col[b0 + lane];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) rc[i] = rv[i];
+            }
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
 #pragma unroll
                 for (int i = 0; i < ND; ++i) y[i] = j == 0 ? S[ND * i] * rc[0] : fma(S[ND * i + j], rc[j], y[i]);
             }
         }
-        qa0 = row_total(y, lane, tile);
+        qa0 = row_total_n<ND>(y, lane, tile);
         if (mine && lane < ND) o_r = a.bhat[ND * (size_t)row + lane];
         const double tau = restrict_row(o_r);
         publish(0.0, 0.0, tau, 0);
@@ -1352,54 +1403,83 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
     // G_r: per cluster slot of the row the sum over its lanes of Shat_rc Zhat_c, one coarse vector at a
     // time (the column's factor is read once; the back substitution multiplies by the reciprocals
     // of its diagonal)
-    if (!flag && mine) {
-        const bool act = lane < nb;
-        const int cc = act ? a.bsr_col[b0 + lane] : row;
-        const double* __restrict__ Fp = a.F + 36 * (size_t)cc;
-        const double* __restrict__ Zc = a.c_z + NV * ND * (size_t)cc;
-        double Fc[15], Fd[ND];          // strict lower triangle (row-major), reciprocal diagonal
-        {
-            int e = 0;
-#pragma unroll
-            for (int l = 1; l < ND; ++l)
-#pragma unroll
-                for (int k = 0; k < l; ++k) Fc[e++] = Fp[ND * l + k];
-#pragma unroll
-            for (int k = 0; k < ND; ++k) Fd[k] = 1.0 / Fp[ND * k + k];
+    if constexpr (ND == 6) {
+        if (!flag && mine) {
+            const bool act = lane < nb;
+            const int cc = act ? a.bsr_col[b0 + lane] : row;
+            const double* __restrict__ Fp = a.F + 36 * (size_t)cc;
+            const double* __restrict__ Zc = a.c_z + NV * ND * (size_t)cc;
+            double Fc[15], Fd[ND];          // strict lower triangle (row-major), reciprocal diagonal
+            {
+                int e = 0;
+    #pragma unroll
+                for (int l = 1; l < ND; ++l)
+    #pragma unroll
+                    for (int k = 0; k < l; ++k) Fc[e++] = Fp[ND * l + k];
+    #pragma unroll
+                for (int k = 0; k < ND; ++k) Fd[k] = 1.0 / Fp[ND * k + k];
+            }
+            double zn[ND];
+    #pragma unroll
+            for (int k = 0; k < ND; ++k) zn[k] = Zc[k];
+    #pragma unroll 1
+            for (int j = 0; j < NV; ++j) {
+                double z[ND], x[ND], P[ND];
+    #pragma unroll
+                for (int k = 0; k < ND; ++k) z[k] = zn[k];
+                if (j + 1 < NV) {
+    #pragma unroll
+                    for (int k = 0; k < ND; ++k) zn[k] = Zc[ND * (j + 1) + k];       // the next vector is on its way
+                }
+                // F' x = z: x[k] = (z[k] - sum_{l > k} F[l][k] x[l]) / F[k][k]
+    #pragma unroll
+                for (int k = ND - 1; k >= 0; --k) {
+                    double v = z[k];
+    #pragma unroll
+                    for (int l = k + 1; l < ND; ++l) v -= Fc[l * (l - 1) / 2 + k] * x[l];
+                    x[k] = v * Fd[k];
+                }
+    #pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    double t = S[ND * i] * x[0];
+    #pragma unroll
+                    for (int k = 1; k < ND; ++k) t = fma(S[ND * i + k], x[k], t);
+                    P[i] = act ? t : 0.0;
+                }
+                for (int sl = 0; sl < n_rowcl && sl < kC2RowCl; ++sl) {
+                    double v[ND];
+    #pragma unroll
+                    for (int i = 0; i < ND; ++i) v[i] = slot == sl ? P[i] : 0.0;
+                    const double tot = row_total_n<ND>(v, lane, tile);
+                    if (lane < ND) Gl[w][sl][lane][j] = tot;
+                }
+            }
         }
-        double zn[ND];
-#pragma unroll
-        for (int k = 0; k < ND; ++k) zn[k] = Zc[k];
+    } else {
+        // the same from the precomputed Zhat (no room for a factor beside a 9 x 9 block)
+        if (!flag && mine) {
+            const bool act = lane < nb;
+            const int cc = act ? a.bsr_col[b0 + lane] : row;
+            const double* __restrict__ Zh = a.c_zhat + NV * ND * (size_t)cc;
 #pragma unroll 1
-        for (int j = 0; j < NV; ++j) {
-            double z[ND], x[ND], P[ND];
+            for (int j = 0; j < NV; ++j) {
+                double x[ND], P[ND];
 #pragma unroll
-            for (int k = 0; k < ND; ++k) z[k] = zn[k];
-            if (j + 1 < NV) {
+                for (int k = 0; k < ND; ++k) x[k] = Zh[ND * j + k];
 #pragma unroll
-                for (int k = 0; k < ND; ++k) zn[k] = Zc[ND * (j + 1) + k];       // the next vector is on its way
-            }
-            // F' x = z: x[k] = (z[k] - sum_{l > k} F[l][k] x[l]) / F[k][k]
+                for (int i = 0; i < ND; ++i) {
+                    double t = S[ND * i] * x[0];
 #pragma unroll
-            for (int k = ND - 1; k >= 0; --k) {
-                double v = z[k];
+                    for (int k = 1; k < ND; ++k) t = fma(S[ND * i + k], x[k], t);
+                    P[i] = act ? t : 0.0;
+                }
+                for (int sl = 0; sl < n_rowcl && sl < kC2RowCl; ++sl) {
+                    double v[ND];
 #pragma unroll
-                for (int l = k + 1; l < ND; ++l) v -= Fc[l * (l - 1) / 2 + k] * x[l];
-                x[k] = v * Fd[k];
-            }
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                double t = S[ND * i] * x[0];
-#pragma unroll
-                for (int k = 1; k < ND; ++k) t = fma(S[ND * i + k], x[k], t);
-                P[i] = act ? t : 0.0;
-            }
-            for (int sl = 0; sl < n_rowcl && sl < kC2RowCl; ++sl) {
-                double v[ND];
-#pragma unroll
-                for (int i = 0; i < ND; ++i) v[i] = slot == sl ? P[i] : 0.0;
-                const double tot = row_total(v, lane, tile);
-                if (lane < ND) Gl[w][sl][lane][j] = tot;
+                    for (int i = 0; i < ND; ++i) v[i] = slot == sl ? P[i] : 0.0;
+                    const double tot = row_total_n<ND>(v, lane, tile);
+                    if (lane < ND) Gl[w][sl][lane][j] = tot;
+                }
             }
         }
     }
@@ -1431,20 +1511,26 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         bool okw = true;
         for (int spins = 1;; ++spins) {
             bool ok = true;
-            double val[ND];
-            int off[ND];
+            constexpr int kFlight = kLean ? 3 : ND;          // loads in flight (register budget)
 #pragma unroll
-            for (int t = 0; t < ND; ++t) off[t] = off_lds[w][t][lane];
+            for (int t0 = 0; t0 < ND; t0 += kFlight) {
+                double val[kFlight];
+                int off[kFlight];
 #pragma unroll
-            for (int t = 0; t < ND; ++t)
-                if (off[t] >= 0) val[t] = ld_shared(vcur + off[t]);
+                for (int t = 0; t < kFlight; ++t) off[t] = off_lds[w][t0 + t][lane];
 #pragma unroll
-            for (int t = 0; t < ND; ++t)
-                if (off[t] >= 0) { ok = ok && !is_sentinel(val[t]); tile[64 * t + lane] = val[t]; }
+                for (int t = 0; t < kFlight; ++t)
+                    if (off[t] >= 0) val[t] = ld_shared(vcur + off[t]);
+#pragma unroll
+                for (int t = 0; t < kFlight; ++t)
+                    if (off[t] >= 0) { ok = ok && !is_sentinel(val[t]); tile[64 * (t0 + t) + lane] = val[t]; }
+            }
             if (__all(ok)) break;
             if (poll.expired(spins)) { okw = false; break; }
         }
-        double y[ND] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double y[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) y[i] = 0.0;
         __builtin_amdgcn_wave_barrier();
         if (okw && lane < nb) {
             const double* u = tile + ND * lane;
@@ -1455,7 +1541,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
                 for (int i = 0; i < ND; ++i) y[i] = j == 0 ? S[ND * i] * wj : fma(S[ND * i + j], wj, y[i]);
             }
         }
-        const double qa = row_total(y, lane, tile);
+        const double qa = row_total_n<ND>(y, lane, tile);
         if (!collect(gen, okw)) { flag = 2; break; }
         if (it == 0) {
             gam0 = gam;
@@ -1465,10 +1551,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
             if (small_gain && gam > a.tol2 * gam0) tol2_met = a.tol2_loose;
             if (!(gam > a.tol2 * gam0) || small_gain || it >= a.max_iter) break;
         }
-        const double beta = it ? gam / gam_prev : 0.0;
+        double beta = it ? gam / gam_prev : 0.0;
+        if constexpr (kLean) beta = to_scalar(beta);
         const double den = del - (it ? beta * gam / alpha_prev : 0.0);
         if (!(den > 0.0)) { flag = 1; break; }               // breakdown: caller falls back
-        const double alpha = gam / den;
+        double alpha = gam / den;
+        if constexpr (kLean) alpha = to_scalar(alpha);
         dq2 = dq1;
         dq1 = 0.5 * alpha * gam;             // what this iteration gains in the quadratic model
         gam_prev = gam;
@@ -1476,6 +1564,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         if (mine && lane < ND) {
             const double m = o_w + own_correction();
             const double n = qa + coarse_row();
+            if constexpr (kLean) { o_z = own[lane]; o_q = own[16 + lane]; o_s = own[32 + lane]; o_p = own[48 + lane]; o_x = own[64 + lane]; }
             o_z = fma(beta, o_z, n);
             o_q = fma(beta, o_q, m);
             o_s = fma(beta, o_s, o_w);
@@ -1484,6 +1573,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
             o_r = fma(-alpha, o_s, o_r);
             o_u = fma(-alpha, o_q, o_u);
             o_w = fma(-alpha, o_z, o_w);
+            if constexpr (kLean) { own[lane] = o_z; own[16 + lane] = o_q; own[32 + lane] = o_s; own[48 + lane] = o_p; own[64 + lane] = o_x; }
         }
         ++it;
     }
@@ -1492,8 +1582,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe2(FusedPcg a) {
         double val = 0.0;
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
-            const double xj = __shfl(o_x, j, 64);
-            if (lane < ND) val += a.F[36 * (size_t)row + ND * j + lane] * xj;
+            const double xj = kLean ? own[64 + j] : __shfl(o_x, j, 64);
+            if (lane < ND) val += a.F[NN * (size_t)row + ND * j + lane] * xj;
         }
         if (lane < ND) a.x[ND * (size_t)row + lane] = val;
     }
@@ -1522,6 +1612,28 @@ size_t pcg_fused_vector_words(int n_cam) { return kSlots * (size_t)n_cam * kVecR
 // Arms every record (all bits set) and the abort word unless that has been done, then launches
 // the solve.  The launch is a plain one and the kernel relies on its admission timeout: a grid
 // that does not become fully resident within admit_ticks aborts and the caller falls back.
+// Zhat_c = F_c^-T Z_c of every camera, [n_cam][7][ND]: thread = (camera, coarse vector).  For the
+// blocks too large for k_pcg_pipe2 to do this itself beside the block it holds.
+template <int ND>
+__global__ __launch_bounds__(kBlock) void k_coarse_zhat(FusedPcg a, double* __restrict__ out) {
+    constexpr int NV = kCoarseVecs;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= a.n_cam * NV) return;
+    const int c = t / NV;
+    const double* __restrict__ F = a.F + ND * ND * (size_t)c;
+    const double* __restrict__ z = a.c_z + (size_t)t * ND;
+    double x[ND];
+#pragma unroll
+    for (int k = ND - 1; k >= 0; --k) {
+        double v = z[k];
+#pragma unroll
+        for (int l = k + 1; l < ND; ++l) v -= F[ND * l + k] * x[l];
+        x[k] = v / F[ND * k + k];
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) out[(size_t)t * ND + k] = x[k];
+}
+
 hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st) {
     if (!armed) {
         hipError_t e = hipMemsetAsync(f.dots, 0xFF, pcg_fused_record_words(f.blocks) * sizeof(unsigned long long), st);
@@ -1531,8 +1643,12 @@ hipError_t launch_pcg_fused(const FusedPcg& f, bool armed, hipStream_t st) {
     }
     FusedPcg arg = f;
     if (f.nd != 6 && !(f.nd == 9 && f.pipelined)) return hipErrorInvalidValue;
-    if (f.coarse && (f.nd != 6 || !f.pipelined)) return hipErrorInvalidValue;
-    if (f.coarse) hipLaunchKernelGGL(k_pcg_pipe2, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    if (f.coarse && !f.pipelined) return hipErrorInvalidValue;
+    if (f.coarse && f.nd == 9) {
+        if (!f.c_zhat) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_coarse_zhat<9>), dim3((f.n_cam * kCoarseVecs + kBlock - 1) / kBlock), dim3(kBlock), 0, st, arg, const_cast<double*>(f.c_zhat));
+        hipLaunchKernelGGL((k_pcg_pipe2<9>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
+    } else if (f.coarse) hipLaunchKernelGGL((k_pcg_pipe2<6>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     else if (f.pipelined && f.nd == 9) hipLaunchKernelGGL((k_pcg_pipe<9>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     else if (f.pipelined) hipLaunchKernelGGL((k_pcg_pipe<6>), dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);
     else hipLaunchKernelGGL(k_pcg_fused, dim3(f.blocks), dim3(kFusedThreads), 0, st, arg);

@@ -168,9 +168,9 @@ def test_a_single_cluster_is_not_built():
 
 # ---- the same coarse space inside the single-launch PCG ------------------------------------
 
-def _solve_single_launch(p, monkeypatch, coarse, **opts):
+def _solve_single_launch(p, monkeypatch, coarse, model="pinhole", **opts):
     monkeypatch.setenv("SFMBA_PCG_FUSED_COARSE", "1" if coarse else "0")
-    with _engine(p, "pinhole", pcg_mode=2, **opts) as eng:
+    with _engine(p, model, pcg_mode=2, **opts) as eng:
         first = eng.solve()
         params = eng.get_params()
         eng.reset_params()
@@ -200,12 +200,23 @@ def test_single_launch_pcg_with_the_coarse_correction(monkeypatch, n_cam):
 
 
 def test_single_launch_coarse_correction_is_skipped_where_its_limits_do_not_hold(monkeypatch):
-    # too few cameras for four clusters of eight: no coarse space at all; the 9-number camera: the
-    # kernel is written for 6 x 6 blocks
+    # too few cameras for four clusters of eight: no coarse space at all
     small = syn.make_problem(28, 700, 3700, seed=22)
     st, _, _ = _solve_single_launch(small, monkeypatch, True, ftol=1e-10)
     assert st.pcg_coarse_solves == 0 and st.pcg_coarse_dim == 0 and st.pcg_single_launch == st.iterations
-    b = _problem("bal", 300, 7500, 39000, seed=23)
-    with _engine(b, "bal", pcg_mode=2, ftol=1e-10) as eng:
-        stb = eng.solve()
-    assert stb.pcg_coarse_solves == 0 and stb.pcg_single_launch == stb.iterations and stb.status > 0
+
+
+@pytest.mark.parametrize("n_cam", [300, 700])
+def test_single_launch_pcg_with_the_coarse_correction_and_the_nine_number_camera(monkeypatch, n_cam):
+    """The same kernel with 9 x 9 blocks (the camera of /root/reference/ba_test.py:78-89; its
+    intrinsics take no part in the coarse space): fewer iterations, the same minimum, repeatable."""
+    b = _problem("bal", n_cam, 25 * n_cam, 130 * n_cam, seed=23)
+    plain, _, (cams0, pts0) = _solve_single_launch(b, monkeypatch, False, model="bal", ftol=1e-10, pcg_rtol=0.03)
+    st, again, (cams1, pts1) = _solve_single_launch(b, monkeypatch, True, model="bal", ftol=1e-10, pcg_rtol=0.03)
+    assert plain.pcg_coarse_solves == 0 and st.pcg_coarse_solves > 0
+    assert st.pcg_single_launch == st.iterations and st.pcg_single_fallbacks == 0 and st.pcg_pipelined == 1
+    assert st.pcg_coarse_dim % 7 == 0 and 4 * 7 <= st.pcg_coarse_dim <= 36 * 7
+    assert st.pcg_iterations < 0.7 * plain.pcg_iterations
+    assert st.status > 0 and abs(st.final_cost - plain.final_cost) <= 1e-6 * plain.final_cost
+    assert np.abs(pts1 - pts0).max() <= 1e-2
+    assert again.final_cost == st.final_cost and again.pcg_iterations == st.pcg_iterations and again.iterations == st.iterations

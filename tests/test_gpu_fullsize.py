@@ -122,7 +122,9 @@ def test_bal_full_solve_converges_to_the_noise_floor_on_both_schur_paths(venice_
         assert abs(st.final_cost - expect) < 0.01 * expect
         assert cams.shape == (venice_bal["n_cameras"], 9) and pts.shape == (venice_bal["n_points"], 3)
         costs.append(st.final_cost)
-    assert abs(costs[0] - costs[1]) <= 1e-6 * costs[0]
+    # (the two paths take different steps - coarse correction and faster damping cuts with the explicit
+    # matrix, block-Jacobi without - and both stop on the ftol rule within a few 1e-6 of the minimum)
+    assert abs(costs[0] - costs[1]) <= 5e-6 * costs[0]
 
 
 def test_two_level_preconditioner_beyond_the_single_launch_solver():
