@@ -96,9 +96,9 @@ typedef struct sfmba_options {
      *       more the operator is set up from that solve's matrix on a second stream while the next
      *       linearisation runs; the solves after it use it, and it is renewed when one of them
      *       takes 48 iterations or more.  Launch-per-iteration solver: two more launches per
-     *       iteration apply it.  Single-launch solver (pinhole
-     *       camera, pipelined form, at most 288 coarse unknowns, rows that reach at most four
-     *       clusters): applied inside the launch, and there also below 256 cameras, with
+     *       iteration apply it.  Single-launch solver (either camera model, pipelined form, at
+     *       most 288 coarse unknowns, rows that reach at most four clusters): applied inside the
+     *       launch, and with the pinhole camera also below 256 cameras, with
      *       clusters as small as eight cameras (the smallest size from n_cameras / 36 up with
      *       which the rows of each of the kernel's workgroups reach at most four clusters; at
      *       least four clusters), switched on after a solve of 12 iterations or more that took

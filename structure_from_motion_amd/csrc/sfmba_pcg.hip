@@ -1060,7 +1060,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_pcg_pipe(FusedPcg a) {
 // adds them in a fixed order, then the workgroup multiplies the rows of C it needs (the clusters of
 // the columns of its rows, at most kC2WgCl x 7 rows, kept in LDS; thread = (row, column mod 16)) -
 // so the coarse correction costs no further trip across the dies, only one more workgroup barrier.
-// Restrictions, checked by the host: those of k_pcg_pipe, 6 x 6 blocks, at most 256 workgroups,
+// Written for ND x ND blocks like k_pcg_pipe.  With ND = 9 the block of a lane leaves no registers
+// for the factor F_c of a column's camera: Zhat of every camera is then formed by k_coarse_zhat in
+// front of the launch, the vectors only the owning lanes update live in LDS, and values every lane
+// holds alike are moved to scalar registers (7.6 us per iteration at 1 778 cameras against 4.4
+// without the correction, for a quarter of the iterations).
+// Restrictions, checked by the host: those of k_pcg_pipe, at most 256 workgroups,
 // clusters of at least 8 cameras whose rows lie in at most kC2Span workgroups, a coarse dimension of
 // at most 288 after padding, at most kC2WgCl clusters among the columns of a workgroup's rows
 // (and so at most kC2RowCl = kC2WgCl among those of one row).
