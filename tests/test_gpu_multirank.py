@@ -194,11 +194,16 @@ def test_sharded_solve_irregular_structure(solver):
         assert abs(o.cost(p, poses, pts) - st["final_cost"]) <= 1e-9 * st["final_cost"]
 
 
-def test_sharded_solve_with_the_coarse_correction_inside_the_single_launch():
+@pytest.mark.parametrize("model", ["pinhole", "bal"])
+def test_sharded_solve_with_the_coarse_correction_inside_the_single_launch(model):
     # 300 cameras: the coarse space exists; every rank sets the operator up from the same all-reduced
     # matrix on its own second stream and applies it inside its own (replicated) single-launch solve
-    p = syn.make_problem(300, 7500, 39000, seed=21)
-    opts = dict(linear_solver=1, schur_mode=2, pcg_mode=2, ftol=1e-10)
+    if model == "bal":
+        p = syn.make_bal_problem(300, 7500, 39000, seed=21)
+        p["K"] = None
+    else:
+        p = syn.make_problem(300, 7500, 39000, seed=21)
+    opts = dict(linear_solver=1, schur_mode=2, pcg_mode=2, ftol=1e-10, camera_model=model)
     with E.Engine(**opts) as eng:
         eng.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
         ref = eng.solve()
