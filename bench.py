@@ -372,7 +372,8 @@ def main():
             # in which every rank keeps the blocks of its own points and the product q = S p is
             # summed over the ranks in every PCG iteration
             cd, cv = (9, 54) if bal else (6, 27)
-            n_c, blocks = int(p["n_cameras"]), int(ps.schur_blocks)
+            n_c = int(p["n_cameras"])
+            blocks = (int(ps.schur_blocks) + n_c) // 2      # upper blocks (schur_blocks counts both orientations)
             lm, pcg = max(1, ps.iterations), ps.pcg_iterations
             small = 8 * (cv * n_c + world) + 8 * 16
             multi["model"] = {
