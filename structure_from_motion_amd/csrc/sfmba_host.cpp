@@ -835,7 +835,10 @@ void do_solve(H* h, sfmba_stats* out) {
     // - where the linear solver copes with little damping: the factorisation, or PCG with the coarse
     // correction at hand; block-Jacobi PCG alone pays for every cut with more iterations (measured with
     // the 9-number camera at the Venice shape: twice the PCG iterations, no outer iteration saved)
-    const bool low_damping_ok = h->use_dense || (h->explicit_schur && (h->fused_pcg ? h->fused_coarse_ok : h->coarse_built));
+    // ... or PCG on the explicit matrix of fewer than 256 cameras, whose iterations cost microseconds: there
+    // the slow cut left the 9-number camera above SciPy's final cost in 5 of 14 seeded problems of 40 to
+    // 130 cameras (by up to 4e-5), the fast one in none, with fewer iterations of either kind
+    const bool low_damping_ok = h->use_dense || (h->explicit_schur && (h->n_cam < 256 || (h->fused_pcg ? h->fused_coarse_ok : h->coarse_built)));
     // (the camera with its own intrinsics is the less linear model: a tenth there - on starts ten times
     // as far off as usual the thirtyfold cut took 13 iterations and stopped 3e-4 above the converged
     // cost, the tenfold one 6 iterations to within 1e-6, and both take 3 on ordinary starts)

@@ -1,0 +1,43 @@
+"""GPU: the reference's acceptance rule - final cost <= SciPy's x (1 + 1e-6) at the reference's
+tolerances (least_squares kwargs of /root/reference/bundle_adjustment.py:141 and ba_test.py:125-126)
+- on seeded problems of many sizes, visibility windows and starts, both camera models, every
+solver the library chooses by itself (factorisation up to 48 cameras, single-launch PCG above)."""
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as o, bal_oracle as b
+from structure_from_motion_amd import synthetic as syn
+from structure_from_motion_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(2468)
+    out = []
+    for k in range(30):
+        model = "bal" if k % 2 else "pinhole"
+        nc = int(rng.choice([3, 6, 12, 20, 33, 40, 47, 49, 64, 90, 130]))
+        npts = int(nc * rng.integers(20, 60))
+        window = int(min(nc, rng.integers(3, 13)))
+        nobs = min(int(npts * rng.uniform(2.0, 5.0)) if nc > 3 else 2 * npts, window * npts)
+        hard = float(rng.choice([1.0, 1.0, 3.0, 8.0]))
+        out.append(pytest.param(model, nc, npts, nobs, window, hard, 3000 + k, id=f"{model}-{nc}cams-x{hard:.0f}-{k}"))
+    return out
+
+
+@pytest.mark.parametrize("model,nc,npts,nobs,window,hard,seed", _cases())
+def test_final_cost_is_scipys_or_better(model, nc, npts, nobs, window, hard, seed):
+    kw = dict(seed=seed, window=window, rot_sigma=0.005 * hard, trans_sigma=0.01 * hard, point_sigma=0.01 * hard)
+    if model == "bal":
+        p = syn.make_bal_problem(nc, npts, nobs, **kw)
+        p["K"] = None
+        ref = b.solve_reference(p)
+    else:
+        p = syn.make_problem(nc, npts, nobs, **kw)
+        ref = o.solve_reference(p)
+    with Engine(camera_model=model) as e:
+        e.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
+        st = e.solve()
+    assert st.status > 0
+    assert st.final_cost <= ref["cost"] * (1 + 1e-6)
