@@ -19,6 +19,7 @@ for k in range(n):
     npts = int(nc * rng.integers(20, 80))
     nobs = int(npts * rng.uniform(2.0, 5.0)) if nc > 3 else 2 * npts
     window = int(min(nc, rng.integers(3, 13)))
+    if os.environ.get("SFMBA_SWEEP_WINDOW"): window = int(os.environ["SFMBA_SWEEP_WINDOW"])
     nobs = min(nobs, window * npts)
     hard = float(rng.choice([1.0, 1.0, 3.0, 8.0]))
     seed = 1000 + k
@@ -29,12 +30,12 @@ for k in range(n):
     else:
         p = syn.make_problem(nc, npts, nobs, **kw)
         ref = o.solve_reference(p)
-    with Engine(camera_model=model) as e:
+    with Engine(camera_model=model, verbose=3 if os.environ.get("SFMBA_SWEEP_VERBOSE") == str(k) else 0) as e:
         e.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
         st = e.solve()
     rel = st.final_cost / ref["cost"] - 1
     worst[model] = max(worst[model], rel)
     flag = "  <-- above SciPy" if rel > 1e-6 else ""
     print(f"{model:7s} cams {nc:3d} pts {npts:5d} obs {nobs:6d} window {window:2d} start x{hard:.0f}: scipy {ref['cost']:.6f} nfev {ref['nfev']:2d} | "
-          f"engine {rel:+.1e} it {st.iterations} pcg {st.pcg_iterations} solver {st.linear_solver} status {st.status}{flag}", flush=True)
+          f"engine {rel:+.1e} it {st.iterations} pcg {st.pcg_iterations} solver {st.linear_solver} status {st.status} {1e3 * st.solve_seconds:.2f} ms{flag}", flush=True)
 print("worst relative excess over SciPy:", worst, flush=True)

@@ -881,7 +881,8 @@ void do_solve(H* h, sfmba_stats* out) {
     double step_norm = 0.0, actual = 0.0;
     const bool talk = o.verbose >= 2 && o.rank <= 0;
     if (talk) { print_header(h); print_row(h, 0, st.nfev, cost, actual, step_norm, g_norm, true); }
-    int accepted = 0;
+    int accepted = 0, held_back_steps = 0;
+    double lambda_rejected = 0.0;
     if (g_norm < gtol) status = SFMBA_STATUS_GTOL;
     // Unless every iteration is printed, the gradient norm of a new linearisation is not waited
     // for: it is read with the scalars of the next trial step (one host synchronisation less per
@@ -987,7 +988,12 @@ void do_solve(H* h, sfmba_stats* out) {
         const double rho = (pred > 0 && std::isfinite(cost_new)) ? actual / pred : -1.0;
         step_norm = std::sqrt(sc[SLOT_STEP2_PT] + sc[SLOT_STEP2_CAM]);
         const double x_norm = std::sqrt(sc[SLOT_X2_PT] + sc[SLOT_X2_CAM]);
-        const bool ft = actual < ftol * cost && rho > 0.25;
+        // A step taken at a damping that a rejection has just raised is short because it was held
+        // back, not because the iterate has converged: its small reduction does not end the run (SciPy's
+        // trust region shrinks by quarters; the damping here may jump a hundredfold).  At most four
+        // such steps in a row are passed over.
+        const bool held_back = exact_steps && nu > 2.0 && held_back_steps < 4;
+        const bool ft = actual < ftol * cost && rho > 0.25 && !held_back;
         const bool xt = step_norm < xtol * (xtol + x_norm);
         if (o.verbose >= 3 && o.rank <= 0)
             emit(h, "  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e pcg %d%s\n", it, cost, cost_new, rho, lambda, step_norm,
@@ -995,7 +1001,17 @@ void do_solve(H* h, sfmba_stats* out) {
         if (rho > 1e-3) {
             h->cur ^= 1;
             ++accepted;
-            lambda = std::max(lambda * std::max(lm_down, 1.0 - std::pow(2.0 * rho - 1.0, 3)), lambda_floor);
+            held_back_steps = nu > 2.0 ? held_back_steps + 1 : 0;
+            {
+                // (after a rejection the damping is not cut back to where that step failed: it stays
+                // above three times the rejected value, a bound that halves with every accepted step;
+                // without it a well-predicted step at 1e-5 sent the damping to 1e-6, where the next step
+                // failed, up again, and round in a cycle of three)
+                double next = lambda * std::max(lm_down, 1.0 - std::pow(2.0 * rho - 1.0, 3));
+                if (lambda_rejected > 0.0) next = std::max(next, std::min(lambda, 3.0 * lambda_rejected));
+                lambda_rejected *= 0.5;
+                lambda = std::max(next, lambda_floor);
+            }
             nu = 2.0;
             cost = cost_new;
             // also the gradient norm at the new iterate; damps for the next step, unless this was the last
@@ -1009,7 +1025,10 @@ void do_solve(H* h, sfmba_stats* out) {
             else if (xt) status = SFMBA_STATUS_XTOL;
             else if (!lin_pending && g_norm < gtol) status = SFMBA_STATUS_GTOL;
         } else {
-            lambda = exact_steps && lambda < 1e-4 / nu ? 1e-4 : lambda * nu;
+            lambda_rejected = lambda;
+            // (exact steps start at the damping floor: a failure there goes straight to the 1e-4 of the
+            // other case instead of doubling twenty times)
+            lambda = exact_steps && lambda < 1e-8 ? 1e-4 : lambda * std::max(nu, exact_steps ? 4.0 : 2.0);
             nu *= 2.0;
             if (xt || lambda > 1e32) status = SFMBA_STATUS_XTOL;
         }
@@ -1203,6 +1222,12 @@ SchurPlan sfmba::plan_schur(H* h) {
     // an exact step lets the damping fall to its floor, and the Gauss-Newton steps that follow are
     // what SciPy's trust-region solver takes on them (scipy/optimize/_lsq/trf.py:473-499).
     int auto_dense_dim = 288;          // up to 48 six-number cameras: nine block rows of the single-launch factorisation
+    // Two-view tracks - what the reference's own correspondence table holds, two observations per
+    // point (WorldPoints.py:40-43) - leave the scale of every camera pair free: the cost has a flat
+    // valley along which damped, inexact steps crawl (on seeded chains of 49 to 200 cameras PCG ended
+    // up to 4e-2 above SciPy's cost after 4 to 6 times SciPy's evaluations).  Such problems are
+    // factored as far as the single-launch factorisation reaches.
+    if (h->n_obs_all <= (int64_t)(2.5 * (double)h->n_pts_all)) auto_dense_dim = std::min(dense_max, 1536);
     if (const char* e = getenv("SFMBA_DENSE_AUTO_DIM")) auto_dense_dim = atoi(e);
     h->dense_auto = lin == SFMBA_SOLVER_AUTO && mode != 1 && dense_padded((int)std::min<int64_t>(n_red, 1 << 20)) <= auto_dense_dim;
     h->dense_allowed = lin == SFMBA_SOLVER_AUTO && n_red <= dense_max;
