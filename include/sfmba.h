@@ -45,9 +45,11 @@ enum sfmba_status {
 };
 
 enum sfmba_linear_solver {
-    SFMBA_SOLVER_AUTO = 0, /* PCG; a step on which PCG runs out of iterations is re-solved by the dense
-                              Cholesky when 6*n_cameras <= dense_max_dim (sfmba_stats.n_dense counts them) */
-    SFMBA_SOLVER_PCG = 1,  /* block-Jacobi preconditioned CG on the implicit Schur complement */
+    SFMBA_SOLVER_AUTO = 0, /* the dense Cholesky for up to 48 cameras (288 unknowns) and, up to 1536 unknowns,
+                              for two-view tracks (at most 2.5 observations per point); PCG otherwise, and a
+                              step on which PCG runs out of iterations is re-solved by the dense Cholesky
+                              when the unknowns number <= dense_max_dim (sfmba_stats.n_dense counts them) */
+    SFMBA_SOLVER_PCG = 1,  /* preconditioned CG on the reduced camera system (explicit or matrix-free) */
     SFMBA_SOLVER_DENSE = 2 /* explicit Schur complement + fp64 MFMA blocked Cholesky */
 };
 
@@ -62,8 +64,10 @@ typedef struct sfmba_options {
     /* Levenberg-Marquardt / linear solver controls (no counterpart in the reference). */
     int32_t max_iterations;   /* cap on LM iterations (accepted + rejected); 0 = 200 */
     double initial_lambda;    /* initial damping; 0 = chosen by the library: 1e-4, or 1e-10 where the camera system is factored exactly */
-    double pcg_rtol;          /* PCG stops at sqrt(r'M^-1 r / r0'M^-1 r0) <= pcg_rtol; 0 = choose: 0.03 where the
-                                 single-launch solver runs (its iterations are cheap), 0.1 otherwise */
+    double pcg_rtol;          /* > 0: PCG stops at sqrt(r'M^-1 r / r0'M^-1 r0) <= pcg_rtol.  0 = choose: inside
+                                 sfmba_solve a linear solve stops once that ratio has passed 0.03 (single-launch
+                                 solver; 0.1 with a launch per iteration) AND its last two iterations each lowered
+                                 the quadratic model by at most 0.05 ftol cost, or at a thirtieth of that ratio */
     int32_t pcg_max_iter;     /* 0 = 1000 */
     int32_t pcg_batch;        /* PCG iterations queued per host check; 0 = 4 (pipelined), 1 = check every iteration */
     int32_t linear_solver;    /* enum sfmba_linear_solver */
