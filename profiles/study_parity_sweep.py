@@ -30,6 +30,12 @@ for k in range(n):
     else:
         p = syn.make_problem(nc, npts, nobs, **kw)
         ref = o.solve_reference(p)
+    if os.environ.get("SFMBA_SWEEP_OUTLIERS"):
+        # gross errors in a fraction of the image points (the reference has no robust loss: they stay in the cost)
+        frac = float(os.environ["SFMBA_SWEEP_OUTLIERS"])
+        bad = rng.random(p["points_2d"].shape[0]) < frac
+        p["points_2d"] = p["points_2d"] + bad[:, None] * rng.normal(0.0, 60.0, p["points_2d"].shape)
+        ref = (b if model == "bal" else o).solve_reference(p)
     with Engine(camera_model=model, verbose=3 if os.environ.get("SFMBA_SWEEP_VERBOSE") == str(k) else 0) as e:
         e.set_problem(p["camera_params"], p["points_3d"], p["camera_indices"], p["point_indices"], p["points_2d"], p["K"])
         st = e.solve()

@@ -19,8 +19,9 @@
 // of Z for a camera nobody observes).  E is small
 // (7 x clusters) and dense; it is assembled from the block-CSR matrix once per damping, scaled to
 // unit diagonal and inverted in place by a blocked Gauss-Jordan sweep, one launch per 32 columns.
-// Each PCG iteration then costs two more small launches: the restriction Z' r and the
-// prolongation z += Z E^-1 (Z' r), which also takes over the r'z partials from k_pcg_update.
+// Each PCG iteration then costs one more small launch: the prolongation z += Z E^-1 (Z' r), which
+// also takes over the r'z partials from k_pcg_update; the restriction Z' r is formed by k_pcg_update
+// itself (per workgroup and cluster) and by a kernel of its own only for the first residual of a solve.
 // All sums run in a fixed order, so the result is the same from run to run.
 #include "sfmba_internal.h"
 
@@ -273,7 +274,10 @@ __global__ __launch_bounds__(kBlock) void k_coarse_restrict(Dev d, Coarse k, int
 // z += Z D Einv rc and the r'z partials; thread = (camera, row) as in k_pcg_update.  A workgroup's
 // cameras lie in at most two clusters (a cluster is never smaller than a workgroup's share of
 // cameras): it forms the up to 14 entries of y = D Einv rc it needs itself, one wavefront per row.
-template <int ND>
+// kFromParts: rc is put together here from what k_pcg_update left per workgroup and cluster slot
+// (a cluster's cameras span a few consecutive workgroups of that kernel; it is the second cluster of
+// the first of them unless it begins where that workgroup does, and the first of all the others).
+template <int ND, bool kFromParts>
 __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int state) {
     constexpr int kCams = kBlock / ND;
     __shared__ double red[16];
@@ -299,7 +303,23 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
         for (int j = threadIdx.x; j < k.n_pad; j += 2 * kBlock) {
             // (n_pad is a multiple of 32, not of the workgroup: the second column is clamped and masked)
             const int j2 = min(j + kBlock, k.n_pad - 1);
-            const double rj = k.rc[j], rj2 = j + kBlock < k.n_pad ? k.rc[j2] : 0.0;
+            double rj, rj2;
+            if constexpr (kFromParts) {
+                auto restricted = [&](int col) {
+                    if (col >= k.n) return 0.0;
+                    const int I = col / kVecs, a = col - kVecs * I;
+                    const int lo = k.cl_ptr[I], hi = k.cl_ptr[I + 1];
+                    const int w0 = lo / kCams, w1 = (hi - 1) / kCams;
+                    double t = k.rpart[2 * kVecs * (size_t)w0 + (lo - kCams * w0 != 0 ? kVecs : 0) + a];
+                    for (int w = w0 + 1; w <= w1; ++w) t += k.rpart[2 * kVecs * (size_t)w + a];
+                    return k.scale[col] * t;
+                };
+                rj = restricted(j);
+                rj2 = j + kBlock < k.n_pad ? restricted(j2) : 0.0;
+            } else {
+                rj = k.rc[j];
+                rj2 = j + kBlock < k.n_pad ? k.rc[j2] : 0.0;
+            }
             double e[kRows], e2[kRows];
 #pragma unroll
             for (int q = 0; q < kRows; ++q) {
@@ -372,14 +392,17 @@ const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st,
 
 // z = M_J^-1 r is in pz and r in pr: adds the coarse correction and rewrites the r'z partials.
 // `state` names the PcgState whose `done` flag gates the work.
-void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st) {
-    const dim3 blk(kBlock);
-    if (d.model == MODEL_BAL) {
+void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st, bool from_parts) {
+    const dim3 blk(kBlock), grid(pcg_update_blocks(d));
+    if (from_parts) {
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_prolong<Bal::ND, true>), grid, blk, 0, st, d, k, state);
+        else hipLaunchKernelGGL((k_coarse_prolong<Pinhole::ND, true>), grid, blk, 0, st, d, k, state);
+    } else if (d.model == MODEL_BAL) {
         hipLaunchKernelGGL((k_coarse_restrict<Bal::ND>), dim3(k.n_cl), blk, 0, st, d, k, state);
-        hipLaunchKernelGGL((k_coarse_prolong<Bal::ND>), dim3(pcg_update_blocks(d)), blk, 0, st, d, k, state);
+        hipLaunchKernelGGL((k_coarse_prolong<Bal::ND, false>), grid, blk, 0, st, d, k, state);
     } else {
         hipLaunchKernelGGL((k_coarse_restrict<Pinhole::ND>), dim3(k.n_cl), blk, 0, st, d, k, state);
-        hipLaunchKernelGGL((k_coarse_prolong<Pinhole::ND>), dim3(pcg_update_blocks(d)), blk, 0, st, d, k, state);
+        hipLaunchKernelGGL((k_coarse_prolong<Pinhole::ND, false>), grid, blk, 0, st, d, k, state);
     }
 }
 

@@ -178,7 +178,8 @@ struct HandleData {
     int64_t coarse_solves = 0;
     int coarse_from = 0;         // switched on after a solve of this many iterations
     DBuf<int> cl_ptr, cam_cl, cpair_i, cpair_j, cpair_cptr, cchunk_beg, cpair_blk, cpair_row;
-    DBuf<double> cZ, cE[2], cscale, crc, cpart;
+    DBuf<double> cZ, cE[2], cscale, crc, cpart, crpart;
+    bool fused_restrict = false;           // restriction formed by k_pcg_update (tuning switch, off: measured slower)
     Coarse coarse{};
     // the same coarse space inside the single-launch PCG (k_pcg_pipe2): the operator is set up on
     // copy_stream after a solve that took fused_coarse_from iterations or more and used by the

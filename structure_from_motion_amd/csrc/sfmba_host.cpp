@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -198,7 +199,7 @@ void refresh_dev(H* h) {
     d.V = h->V.p; d.gp = h->gp.p; d.Vinv = h->Vinv.p; d.s = h->s.p; d.s0 = h->s0.p;
     d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p;
     d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp[0] = h->pp[0].p; d.pp[1] = h->pp[1].p; d.pq = h->pq.p; d.qS = h->qS.p;
-    d.pcg = h->pcg.p; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
+    d.pcg = h->pcg.p; d.pcg_mirror = h->pcg_host; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
     // (with a communicator the slots are summed over the ranks on the device and then copied)
     d.scalars_host = h->has_comm() ? nullptr : h->scalars_host;
     d.dot_off = h->dot_off;
@@ -567,9 +568,13 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
         launch_pcg_init(h->dev, tol, max_iter, h->stream, stop.loose, stop.q_abs);
         if (two_level) launch_coarse_apply(h->dev, h->coarse, 0, h->stream);
     }
-    // Iterations are queued in batches; the state of batch k is copied to pinned host memory
-    // behind it and only read after batch k+1 has been queued, so the GPU never waits for the
-    // host.  Kernels queued after convergence return at once (PcgState.done).
+    // Iterations are queued in batches; the head of every iteration writes its state into pinned
+    // host memory as well (all fields, a fence, then `done`), an event marks the end of batch k and
+    // the host looks at the state only after batch k+1 has been queued, so the GPU never waits for
+    // the host - and no copy sits between the batches (a device-to-host copy in the stream is a
+    // kernel of its own: 6 us and a 4 us bubble per batch).  What the host reads may already
+    // belong to an iteration of batch k+1: it only acts on `done`, after which the record no longer
+    // changes.  Kernels queued after convergence return at once (PcgState.done).
     int batch = h->opt.pcg_batch > 0 ? h->opt.pcg_batch : 4;
     int cur = 0, queued = 0;
     auto queue_batch = [&](int slot) {
@@ -600,13 +605,26 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
                 n_pq = h->nb_cam;
             }
             Scope t(h, F_PCGVEC);
-            launch_pcg_update(h->dev, cur, n_pq, h->stream);
-            if (two_level) launch_coarse_apply(h->dev, h->coarse, cur ^ 1, h->stream);
+            // (the restriction of the two-level preconditioner stays a launch of its own: formed inside
+            // k_pcg_update per workgroup and cluster and put together by the prolongation it was measured
+            // 4 us per iteration slower at 13 682 cameras - the seven wavefront sums per cluster slot and
+            // the prolongation's two extra dependent loads cost more than the launch they replace;
+            // SFMBA_PCG_FUSED_RESTRICT=1 selects that form)
+            launch_pcg_update(h->dev, cur, n_pq, h->stream, two_level && h->fused_restrict ? &h->coarse : nullptr);
+            if (two_level) launch_coarse_apply(h->dev, h->coarse, cur ^ 1, h->stream, h->fused_restrict);
             cur ^= 1;
             ++queued;
         }
-        HIP_TRY(hipMemcpyAsync(&h->pcg_host[slot], h->pcg.p + cur, sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipEventRecord(h->pcg_ev[slot], h->stream));
+    };
+    auto read_state = [&]() {
+        const volatile PcgState* m = h->pcg_host;
+        PcgState s{};
+        s.done = m->done;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        s.rz = m->rz; s.rz0 = m->rz0; s.tol2 = m->tol2; s.tol2_loose = m->tol2_loose; s.q_abs = m->q_abs;
+        s.iter = m->iter; s.max_iter = m->max_iter;
+        return s;
     };
     const bool pipelined = batch > 1;
     int slot = 0;
@@ -615,8 +633,15 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
     for (;;) {
         if (pipelined) queue_batch(slot ^ 1);
         HIP_TRY(hipEventSynchronize(h->pcg_ev[slot]));
-        st = h->pcg_host[slot];
-        if (st.done || queued >= max_iter + 2 * batch) break;
+        st = read_state();
+        if (st.done) break;
+        if (queued >= max_iter + 2 * batch) {
+            // (cannot happen while max_iter is what the kernels stop at; the record of the last
+            // iteration queued, at rest)
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            st = read_state();
+            break;
+        }
         if (!pipelined) queue_batch(slot);
         else slot ^= 1;
     }
@@ -1620,12 +1645,15 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
         for (auto& e : h->cE) e.alloc((size_t)k7.n_pad * k7.n_pad);
         h->cscale.alloc((size_t)k7.n_pad); h->crc.alloc((size_t)k7.n_pad);
         h->crc.zero(st);
+        h->crpart.alloc((size_t)((n_cam + kBlock / h->cd - 1) / (kBlock / h->cd)) * 2 * kCoarseVecs);
         HIP_TRY(hipStreamSynchronize(st));
         k7.cl_ptr = h->cl_ptr.p; k7.cam_cl = h->cam_cl.p; k7.cpair_i = h->cpair_i.p; k7.cpair_j = h->cpair_j.p;
         k7.cpair_cptr = h->cpair_cptr.p; k7.cchunk_beg = h->cchunk_beg.p; k7.cpart = h->cpart.p; k7.cpair_blk = h->cpair_blk.p; k7.cpair_row = h->cpair_row.p;
-        k7.Z = h->cZ.p; k7.E[0] = h->cE[0].p; k7.E[1] = h->cE[1].p; k7.scale = h->cscale.p; k7.rc = h->crc.p;
+        k7.Z = h->cZ.p; k7.E[0] = h->cE[0].p; k7.E[1] = h->cE[1].p; k7.scale = h->cscale.p; k7.rc = h->crc.p; k7.rpart = h->crpart.p;
         k7.Einv = k7.E[0];
         h->coarse_built = true;
+        h->fused_restrict = false;
+        if (const char* e = getenv("SFMBA_PCG_FUSED_RESTRICT")) h->fused_restrict = atoi(e) != 0;
         h->coarse_from = kCoarseFromIterations;
         h->coarse_forced = coarse > 0;
         // left to choose, the operator comes from an earlier solve's matrix and is set up beside the

@@ -142,6 +142,7 @@ struct Dev {
     double* px; double* pr; double* pz; double* pq; double* qS;
     double* pp[2];      // search direction, double-buffered by iteration parity
     PcgState* pcg;      // [2], double-buffered by iteration parity
+    PcgState* pcg_mirror;   // pinned host memory: the launch-per-iteration solver writes the state of every iteration there too
     double* dot_part;   // block partials of p'q at [0, dot_off), of r'z at [dot_off, ...)
     int dot_off;        // offset of the r'z partials inside dot_part (p'q partials start at 0)
     // explicit block-sparse Schur complement (sfmba_schur.hip)
@@ -187,6 +188,8 @@ struct Coarse {
     double* E[2];             // [n_pad][n_pad] each: assembly, scaling and the sweep alternate between them
     double* scale;            // [n_pad] D = diag(E)^-1/2
     double* rc;               // [n_pad] restricted residual (zero on the padding)
+    double* rpart;            // [workgroups of k_pcg_update][2][7] the restriction as that kernel leaves it: per workgroup and
+                              // cluster slot (a workgroup's cameras lie in at most two clusters) the sums Z'r over its cameras
     const double* Einv;       // whichever of E[] holds (D E D)^-1
 };
 
@@ -224,7 +227,8 @@ void launch_pcg_spmv_bsr(const Dev& d, int cur, hipStream_t st);            // e
 void launch_pcg_dir(const Dev& d, int cur, hipStream_t st);                 // implicit mode: direction only
 void launch_pcg_q(const Dev& d, double lambda, int cur, hipStream_t st);    // implicit mode: q = U* p - qS
 void launch_pcg_dot(const Dev& d, int cur, hipStream_t st);
-void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st);
+// coarse != nullptr: also leaves the restriction Z'r of the new residual in coarse->rpart (two-level preconditioner)
+void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st, const Coarse* coarse = nullptr);
 // whole PCG solve in one launch (explicit mode); returns the launch error
 int pcg_fused_max_blocks(int device);
 int pcg_fused_rows_per_block();
@@ -258,7 +262,8 @@ void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_coarse.hip
 const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled = nullptr,
                                   void (*sum_over_ranks)(void*, double*, size_t) = nullptr, void* ctx = nullptr);    // returns the buffer holding the inverse
-void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st);  // pz += Z E^-1 Z' pr, r'z partials
+// from_parts: the restriction is taken from k.rpart (left by launch_pcg_update) instead of being formed here
+void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st, bool from_parts = false);  // pz += Z E^-1 Z' pr, r'z partials
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)
 void launch_triangulate(const double* P1, const double* P2, int n, const double2* x1, const double2* x2,
                         double* X, double* err1, double* err2, hipStream_t st);

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_pcg_init(Dev d, double tol, int max_
         st.tol2_loose = tol_loose * tol_loose; st.q_abs = q_abs; st.dq1 = st.dq2 = 1e300;
         d.pcg[0] = st;
         d.pcg[1] = st;
+        if (d.pcg_mirror) d.pcg_mirror[0] = st;
     }
 }
 
@@ -97,12 +98,34 @@ struct Head { bool run; double beta; };
 template <int ND>
 __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch) {
     constexpr int kCams = cams_per_update_block<ND>();
-    const PcgState st = d.pcg[cur];
+    // (the record is read and written field by field: a copy of the whole structure leaves its
+    // untouched tail in a stack slot, which the compiler moves to LDS at an offset it derives from
+    // the workgroup shape in the dispatch packet - a read from host memory by the first wavefront
+    // of every compute unit, 13 us per launch measured on a kernel that did nothing else)
+    const PcgState& in = d.pcg[cur];
+    PcgState st;
+    st.rz = in.rz; st.rz0 = in.rz0; st.tol2 = in.tol2; st.tol2_loose = in.tol2_loose; st.q_abs = in.q_abs;
+    st.dq1 = in.dq1; st.dq2 = in.dq2; st.iter = in.iter; st.max_iter = in.max_iter; st.done = in.done;
+    st.pad = in.pad; st.ticks = in.ticks;
+    auto put = [&](const PcgState& v) {
+        PcgState& o = d.pcg[cur ^ 1];
+        o.rz = v.rz; o.rz0 = v.rz0; o.tol2 = v.tol2; o.tol2_loose = v.tol2_loose; o.q_abs = v.q_abs;
+        o.dq1 = v.dq1; o.dq2 = v.dq2; o.iter = v.iter; o.max_iter = v.max_iter; o.done = v.done;
+        o.pad = v.pad; o.ticks = v.ticks;
+        if (PcgState* m = d.pcg_mirror) {
+            // the host's copy: `done` last, behind a fence, so that a host that sees it set finds the
+            // fields that go with it
+            m->rz = v.rz; m->rz0 = v.rz0; m->tol2 = v.tol2; m->tol2_loose = v.tol2_loose; m->q_abs = v.q_abs;
+            m->iter = v.iter; m->max_iter = v.max_iter;
+            __threadfence_system();
+            m->done = v.done;
+        }
+    };
     Head h;
     h.run = false;
     h.beta = 0.0;
     if (st.done) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg[cur ^ 1] = st;
+        if (blockIdx.x == 0 && threadIdx.x == 0) put(st);
         return h;
     }
     const double rz = block_total(d.dot_part + d.dot_off, (d.n_cam + kCams - 1) / kCams, scratch);
@@ -121,7 +144,7 @@ __device__ __forceinline__ Head pcg_head(const Dev& d, int cur, double* scratch)
     }
     h.run = !nx.done;
     if (h.run) nx.iter = st.iter + 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg[cur ^ 1] = nx;
+    if (blockIdx.x == 0 && threadIdx.x == 0) put(nx);
     return h;
 }
 
@@ -271,8 +294,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_dot(Dev d, int cur) {
 }
 
 // alpha = rz / p'q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; r'z partials.  thread = (camera, row).
-template <int ND>
-__global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_parts) {
+// kRestrict: the two-level preconditioner's restriction of the new residual as well: the sums Z'r over
+// the workgroup's cameras, per cluster (its cameras lie in at most two), into rpart[workgroup][2][7];
+// k_coarse_prolong adds up the workgroups of a cluster.  Saves a launch per iteration.
+template <int ND, bool kRestrict>
+__global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_parts, const double* __restrict__ Z,
+                                                        const int* __restrict__ cam_cl, double* __restrict__ rpart) {
     constexpr int kCams = cams_per_update_block<ND>();
     __shared__ double red[16];
     __shared__ double rs[kBlock];
@@ -301,6 +328,41 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(Dev d, int cur, int n_pq_
         const double z = precond_row<ND>(d.Minv + ND * ND * (size_t)c + ND * k, rs + ND * local);
         d.pz[o] = z;
         dot = rk * z;
+    }
+    if constexpr (kRestrict) {
+        // this thread's share of the seven sums: Z[c][a][k] r_k; summed over the wavefront per cluster
+        // slot, then over the four wavefronts in a fixed order
+        constexpr int kV = kCoarseVecs;
+        __shared__ double wpart[kBlock / 64][2][kV];
+        const int c_first = blockIdx.x * kCams;
+        const int I0 = cam_cl[c_first], I1 = cam_cl[min(c_first + kCams, d.n_cam) - 1];     // uniform
+        const int slot = act ? cam_cl[c] - I0 : 0;
+        double v[kV];
+#pragma unroll
+        for (int a = 0; a < kV; ++a) v[a] = act ? Z[(kV * (size_t)c + a) * ND + k] * rk : 0.0;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int a = 0; a < kV; ++a) {
+            const double t0 = wave_sum(slot == 0 ? v[a] : 0.0);
+            if (lane == 0) wpart[w][0][a] = t0;
+        }
+        if (I1 != I0) {
+#pragma unroll
+            for (int a = 0; a < kV; ++a) {
+                const double t1 = wave_sum(slot == 1 ? v[a] : 0.0);
+                if (lane == 0) wpart[w][1][a] = t1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * kV) {
+            const int sl = threadIdx.x / kV, a = threadIdx.x - kV * sl;
+            double t = 0.0;
+            if (sl == 0 || I1 != I0) {
+#pragma unroll
+                for (int q = 0; q < kBlock / 64; ++q) t += wpart[q][sl][a];
+            }
+            rpart[2 * kV * (size_t)blockIdx.x + threadIdx.x] = t;
+        }
     }
     const double s = block_sum(dot, red);
     if (threadIdx.x == 0) d.dot_part[d.dot_off + blockIdx.x] = s;
@@ -1680,9 +1742,15 @@ void launch_pcg_dot(const Dev& d, int cur, hipStream_t st) {
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_dot<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur);
     else hipLaunchKernelGGL((k_pcg_dot<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur);
 }
-void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st) {
-    if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_update<Bal::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
-    else hipLaunchKernelGGL((k_pcg_update<Pinhole::ND>), dim3(pcg_update_blocks(d)), dim3(kBlock), 0, st, d, cur, n_pq_parts);
+void launch_pcg_update(const Dev& d, int cur, int n_pq_parts, hipStream_t st, const Coarse* coarse) {
+    const dim3 grid(pcg_update_blocks(d)), blk(kBlock);
+    if (coarse) {
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_update<Bal::ND, true>), grid, blk, 0, st, d, cur, n_pq_parts, coarse->Z, coarse->cam_cl, coarse->rpart);
+        else hipLaunchKernelGGL((k_pcg_update<Pinhole::ND, true>), grid, blk, 0, st, d, cur, n_pq_parts, coarse->Z, coarse->cam_cl, coarse->rpart);
+    } else {
+        if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_pcg_update<Bal::ND, false>), grid, blk, 0, st, d, cur, n_pq_parts, nullptr, nullptr, nullptr);
+        else hipLaunchKernelGGL((k_pcg_update<Pinhole::ND, false>), grid, blk, 0, st, d, cur, n_pq_parts, nullptr, nullptr, nullptr);
+    }
 }
 
 }  // namespace sfmba
