@@ -7,6 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# (SFMBA_STUDY_SHAPE in the environment selects another shape)
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/profiles/study_final_shape.py" 0 > "$OUT/trace.out" 2> "$OUT/trace.err"
 f=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] || { echo "trace failed"; tail -5 "$OUT/trace.err"; exit 1; }

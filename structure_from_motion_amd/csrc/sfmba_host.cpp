@@ -320,6 +320,13 @@ void reduce_scalars(H* h, int first, int count) {
 // next linearisation.  It reads the cameras, UG and the reduced matrix only up to the event
 // ev_c_assembled: whatever overwrites those on the main stream waits for that event first (it has
 // long passed by then), and the PCG launch that uses the operator waits for ev_c_done.
+// (Giving the second stream the device's highest priority was measured and changes nothing: a sweep
+// of the coarse operator's chain that is launched while k_schur_pairs runs - one-wavefront workgroups
+// at three per SIMD, refilled one at a time - finds its four wavefront slots on one compute unit only
+// when that kernel's grid is exhausted, 150 instead of 20 us, whatever the priority.)
+void ensure_copy_stream(H* h) {
+    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+}
 void wait_coarse_inputs(H* h) {
     if (h->fused_coarse_ready) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_assembled, 0));
 }
@@ -328,7 +335,7 @@ void start_fused_coarse(H* h) {
         HIP_TRY(hipEventCreateWithFlags(&h->ev_c_assembled, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_c_done, hipEventDisableTiming));
     }
-    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    ensure_copy_stream(h);
     // (the caller has waited for the main stream: the matrix of the solve just finished is in
     // place and no single-launch solve that could still read the last operator is running)
     h->fused_einv = launch_coarse_setup(h->dev, h->coarse, h->copy_stream, h->ev_c_assembled);
@@ -1952,7 +1959,7 @@ void do_set_problem(H* h, int64_t n_cam, int64_t n_pts, int64_t n_obs, const dou
         // The image points (half of the bytes) and the 3-D points go up from a second host thread
         // on a stream of their own while the index work runs on the GPU; the structure needs them
         // only at its very end (device_place_uv, do_set_params).
-        if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        ensure_copy_stream(h);
         hipError_t copy_err = hipSuccess;
         std::thread copier([&] {
             copy_err = hipSetDevice(h->device);
