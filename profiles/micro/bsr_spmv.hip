@@ -48,6 +48,51 @@ __global__ __launch_bounds__(256) void k_rows(M m) {
     }
 }
 
+
+// as k_rows, but a lane loads only its own entry of z and p of the block's column; the six entries
+// of the direction meet in LDS
+__global__ __launch_bounds__(256) void k_rows_lds(M m) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + w;
+    const int sub = lane / 6, k = lane - 6 * sub;
+    __shared__ double part[256];
+    __shared__ double2 dir[4][32];
+    double* mine = reinterpret_cast<double*>(dir[w]);
+    double acc = 0.0;
+    if (c < m.n) {
+        const int b0 = m.ptr[c], b1 = m.ptr[c + 1];
+        for (int base = b0; base < b1; base += 10) {
+            const int b = base + sub;
+            const bool ok = sub < 10 && b < b1;
+            double2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0};
+            double dk = 0.0;
+            if (ok) {
+                const size_t col = 6 * (size_t)m.col[b];
+                const double2* s = reinterpret_cast<const double2*>(m.S + 36 * (size_t)b + 6 * k);
+                s0 = s[0]; s1 = s[1]; s2 = s[2];
+                dk = m.z[col + k] + m.beta * m.p[col + k];
+            }
+            mine[lane] = dk;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (ok) {
+                const double2* dv = dir[w] + 3 * sub;
+                const double2 d0 = dv[0], d1 = dv[1], d2 = dv[2];
+                acc += s0.x * d0.x + s0.y * d0.y + s1.x * d1.x + s1.y * d1.y + s2.x * d2.x + s2.y * d2.y;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (c < m.n && lane < 6) {
+        double q = 0.0;
+        for (int s = 0; s < 10; ++s) q += part[64 * w + lane + 6 * s];
+        m.q[6 * (size_t)c + lane] = q;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_stream(M m) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + w;
@@ -291,6 +336,7 @@ int main() {
     };
     const int wgs = (n + 3) / 4;
     time("rows", true, [&] { hipLaunchKernelGGL((k_rows<true, true>), dim3(wgs), dim3(256), 0, 0, m); });
+    time("rows_lds", true, [&] { hipLaunchKernelGGL(k_rows_lds, dim3(wgs), dim3(256), 0, 0, m); });
     time("rows_noS", false, [&] { hipLaunchKernelGGL((k_rows<false, true>), dim3(wgs), dim3(256), 0, 0, m); });
     time("rows_noV", false, [&] { hipLaunchKernelGGL((k_rows<true, false>), dim3(wgs), dim3(256), 0, 0, m); });
     time("stream", false, [&] { hipLaunchKernelGGL(k_stream, dim3(wgs), dim3(256), 0, 0, m); });

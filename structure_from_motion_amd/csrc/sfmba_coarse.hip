@@ -365,14 +365,17 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
 
 // Builds Z, E = Z'SZ and its inverse; returns the buffer that holds D^-1 E^-1 D^-1 (k.scale = D).
 // `assembled`, when given, is recorded once nothing of the problem (cameras, UG, the matrix) is
-// read any more: what follows works on the coarse matrices alone.
+// read any more: what follows works on the coarse matrices alone; `basis_done` as soon as the
+// cameras and UG are not (the first kernel), after which only the reduced matrix is still read.
 // `sum_over_ranks`, when given, is called on E once it is assembled (on `st`): with the reduced matrix
 // split over the ranks E = Z'SZ is the sum of the ranks' Z'S_k Z.
 const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled,
-                                  void (*sum_over_ranks)(void*, double*, size_t), void* ctx) {
+                                  void (*sum_over_ranks)(void*, double*, size_t), void* ctx, hipEvent_t basis_done) {
     const dim3 blk(kBlock);
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_basis<Bal>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
     else hipLaunchKernelGGL((k_coarse_basis<Pinhole>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
+    // (the cameras and U have been read: from here on only the reduced matrix is)
+    if (basis_done) (void)hipEventRecord(basis_done, st);
     const size_t total = (size_t)k.n_pad * k.n_pad;
     (void)hipMemsetAsync(k.E[0], 0, total * sizeof(double), st);
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_assemble<Bal::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);

@@ -194,7 +194,7 @@ struct HandleData {
     double solve_rtol = 0.0;          // PCG tolerance of the sfmba_solve in progress (0 outside one)
     double model_gain_floor = -1.0;   // inside a solve: a PCG iteration that lowers the model by less than this is not worth its time (< 0: rule off)
     DBuf<int> wg_cl;
-    hipEvent_t ev_c_assembled = nullptr, ev_c_done = nullptr;
+    hipEvent_t ev_c_basis = nullptr, ev_c_assembled = nullptr, ev_c_done = nullptr;
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
     bool dense_allowed = false;  // small enough for the dense fallback
@@ -231,6 +231,7 @@ struct HandleData {
         for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
         if (pcg_host) (void)hipHostFree(pcg_host);
         if (scalars_host) (void)hipHostFree(scalars_host);
+        if (ev_c_basis) (void)hipEventDestroy(ev_c_basis);
         if (ev_c_assembled) (void)hipEventDestroy(ev_c_assembled);
         if (ev_c_done) (void)hipEventDestroy(ev_c_done);
         if (comm && comm_destroy) comm_destroy(comm);

@@ -317,9 +317,9 @@ void reduce_scalars(H* h, int first, int count) {
 // them only with those of the trial step that follows: they are finished by that step's launch
 // (phase_trial) instead of two small launches of their own.
 // The coarse operator of the single-launch PCG is set up on copy_stream beside the kernels of the
-// next linearisation.  It reads the cameras, UG and the reduced matrix only up to the event
-// ev_c_assembled: whatever overwrites those on the main stream waits for that event first (it has
-// long passed by then), and the PCG launch that uses the operator waits for ev_c_done.
+// next linearisation.  It reads the cameras and UG up to the event ev_c_basis and the reduced matrix
+// up to ev_c_assembled: whatever overwrites those on the main stream waits for the event first, and
+// the PCG launch that uses the operator waits for ev_c_done.
 // (Giving the second stream the device's highest priority was measured and changes nothing: a sweep
 // of the coarse operator's chain that is launched while k_schur_pairs runs - one-wavefront workgroups
 // at three per SIMD, refilled one at a time - finds its four wavefront slots on one compute unit only
@@ -327,18 +327,25 @@ void reduce_scalars(H* h, int first, int count) {
 void ensure_copy_stream(H* h) {
     if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 }
-void wait_coarse_inputs(H* h) {
+// Two waits: what rewrites U or the cameras (the camera-major pass of a linearisation) waits for the
+// set-up's first kernel only; what rewrites the reduced matrix (the finishing passes of phase_damp)
+// for its assembly, which at 13 682 cameras takes as long as the point-major pass beside it.
+void wait_coarse_basis(H* h) {
+    if (h->fused_coarse_ready) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_basis, 0));
+}
+void wait_coarse_matrix(H* h) {
     if (h->fused_coarse_ready) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_assembled, 0));
 }
 void start_fused_coarse(H* h) {
     if (!h->ev_c_done) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_c_basis, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_c_assembled, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_c_done, hipEventDisableTiming));
     }
     ensure_copy_stream(h);
     // (the caller has waited for the main stream: the matrix of the solve just finished is in
     // place and no single-launch solve that could still read the last operator is running)
-    h->fused_einv = launch_coarse_setup(h->dev, h->coarse, h->copy_stream, h->ev_c_assembled);
+    h->fused_einv = launch_coarse_setup(h->dev, h->coarse, h->copy_stream, h->ev_c_assembled, nullptr, nullptr, h->ev_c_basis);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_c_done, h->copy_stream));
     h->fused_coarse_ready = true;
@@ -365,7 +372,7 @@ void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false, bool def
     // of its launches falls into that kernel's run)
     if (h->fused_coarse_wanted && !grad_only) start_fused_coarse(h);
     h->fused_coarse_wanted = false;
-    wait_coarse_inputs(h);
+    wait_coarse_basis(h);
     h->lin_owed = defer;
     h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
     h->have_v = !grad_only && !(lambda > 0.0);
@@ -404,7 +411,7 @@ void damp_points(H* h, double lambda) {
 // mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
     if (h->fused_coarse_wanted) { start_fused_coarse(h); h->fused_coarse_wanted = false; }   // (after a rejected step)
-    wait_coarse_inputs(h);
+    wait_coarse_basis(h);
     if (h->explicit_schur) {
         // per camera, behind the blocks: T_c = sum W Vinv W' (its own observations: the diagonal
         // block's share) and sum W Vinv g_p (the point part of the right-hand side)
@@ -446,6 +453,7 @@ void phase_damp(H* h, double lambda) {
         }
         {
             Scope t(h, F_SCHUR);
+            wait_coarse_matrix(h);
             launch_schur_finish(h->dev, lambda, tpart, h->fused_pcg ? &h->fused : nullptr, h->stream,
                                 h->split && h->has_comm() ? 1.0 / h->opt.nranks : 1.0);
             h->fused_armed = h->fused_pcg;
@@ -1561,6 +1569,7 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     // cube of their number, the iteration count with their size; measured best at the Venice shape
     // with 48 and at the Final shape with 128)
     int coarse_k = coarse > 0 ? std::max(coarse, 48) : std::min(128, std::max(48, n_cam / 100));
+    if (const char* e = getenv("SFMBA_COARSE_K")) coarse_k = std::max(48, atoi(e));      // tuning: cameras per cluster
     coarse_k = std::max(coarse_k, (int)((7LL * n_cam + 4095) / 4096));
     // Where the single-launch solver will apply the correction itself (k_pcg_pipe2), the vector
     // kernels' limit does not hold: clusters go down to the eight camera rows of one of its

@@ -261,7 +261,8 @@ void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_coarse.hip
 const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled = nullptr,
-                                  void (*sum_over_ranks)(void*, double*, size_t) = nullptr, void* ctx = nullptr);    // returns the buffer holding the inverse
+                                  void (*sum_over_ranks)(void*, double*, size_t) = nullptr, void* ctx = nullptr,
+                                  hipEvent_t basis_done = nullptr);    // returns the buffer holding the inverse
 // from_parts: the restriction is taken from k.rpart (left by launch_pcg_update) instead of being formed here
 void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st, bool from_parts = false);  // pz += Z E^-1 Z' pr, r'z partials
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)
