@@ -191,6 +191,7 @@ struct HandleData {
     int fused_prev_iter = 0;           // iterations of the single-launch solve before the last one (0: none yet in this run)
     const double* fused_einv = nullptr;
     bool fused_coarse_wanted = false; // set up an operator beside the next linearisation
+    bool coarse_start_pending = false; // ... or right behind the trial step that follows the solve which asked for it
     double solve_rtol = 0.0;          // PCG tolerance of the sfmba_solve in progress (0 outside one)
     double model_gain_floor = -1.0;   // inside a solve: a PCG iteration that lowers the model by less than this is not worth its time (< 0: rule off)
     DBuf<int> wg_cl;

@@ -673,11 +673,18 @@ PcgState phase_pcg(H* h, double lambda, bool allow_fused = true) {
     } else if (h->explicit_schur && h->coarse_built && !h->coarse_failed && !h->coarse_async && st.iter >= h->coarse_from) {
         h->coarse_on = true;        // solves only get longer as the damping falls
     }
-    // (with the operator set up on the second stream the switch-on rule sits in do_solve, which
-    // knows when the next linearisation starts)
+    // With the operator set up on the second stream: the set-up starts here, as soon as the solve
+    // that asks for it is known to be over, beside the trial step and the next linearisation.  (It
+    // used to start with the linearisation: at 13 682 cameras its 24 sweeps then ran into
+    // k_schur_pairs, beside which a sweep starves - 1 ms for one of them - and the next solve waited
+    // 0.45 ms for the operator.)  The solve has converged when the host sees `done`: what is still
+    // queued of it returns at once and reads nothing of the coarse operator, the matrix stays as it
+    // is until the finishing passes of the next damping, which wait for the set-up's assembly.
     if (h->explicit_schur && h->coarse_built && h->coarse_async && !h->coarse_failed && !h->coarse_on && !h->fused_pcg &&
-        h->solve_rtol > 0 && st.iter >= (two_level ? 4 * h->coarse_from : h->coarse_from))
-        h->fused_coarse_wanted = true;
+        h->solve_rtol > 0 && st.iter >= (two_level ? 4 * h->coarse_from : h->coarse_from)) {
+        if (st.done) h->coarse_start_pending = true;
+        else h->fused_coarse_wanted = true;
+    }
     return st;
 }
 
@@ -866,7 +873,7 @@ void do_solve(H* h, sfmba_stats* out) {
     h->fused_prev_iter = 0;
     for (int f = 0; f < F_COUNT; ++f) { h->fam_ms[f] = 0; h->fam_n[f] = 0; }
     h->coarse_on = h->coarse_forced; h->coarse_failed = false; h->coarse_solves = 0;
-    h->fused_coarse_ready = false; h->fused_coarse_wanted = false;
+    h->fused_coarse_ready = false; h->fused_coarse_wanted = false; h->coarse_start_pending = false;
     h->solve_rtol = 0.0;
     h->solve_rtol = pcg_rtol_of(h);
     struct ClearRtol { H* h; ~ClearRtol() { h->solve_rtol = 0.0; h->model_gain_floor = -1.0; } } clear_rtol{h};
@@ -948,6 +955,13 @@ void do_solve(H* h, sfmba_stats* out) {
             HIP_TRY(hipMemsetAsync(h->scalars.p + SLOT_PCGFLAG, 0, sizeof(double), h->stream));
         }
         phase_trial(h, nullptr);
+        if (h->coarse_start_pending) {
+            // (queued behind the trial step: the thirty launches of the set-up take the host 0.4 ms,
+            // which the trial step's kernel covers)
+            h->coarse_start_pending = false;
+            if (getenv("SFMBA_COARSE_START_LATE")) h->fused_coarse_wanted = true;
+            else start_fused_coarse(h);
+        }
         if (lin_pending) {
             g_norm = read_lin_scalars(h, sc);
             lin_pending = false;
