@@ -23,6 +23,8 @@
 // also takes over the r'z partials from k_pcg_update; the restriction Z' r is formed by k_pcg_update
 // itself (per workgroup and cluster) and by a kernel of its own only for the first residual of a solve.
 // All sums run in a fixed order, so the result is the same from run to run.
+#include <cstdlib>
+
 #include "sfmba_internal.h"
 
 namespace sfmba {
@@ -146,14 +148,21 @@ __global__ __launch_bounds__(kBlock) void k_coarse_scale(Coarse k, const double*
 // One workgroup per 32 x 32 tile; it reads `src` and writes `dst`, so no tile sees a value of this
 // step.  Every workgroup inverts the pivot block itself (in LDS, unpivoted: the matrix is
 // symmetric positive definite with unit diagonal), which is cheaper than a launch of its own.
-__global__ __launch_bounds__(kBlock) void k_coarse_gj(const double* __restrict__ src, double* __restrict__ dst, int n_pad, int p) {
+// kThreads = 64 (SFMBA_GJ_WAVES=1) is the same sweep with one wavefront per tile, sixteen entries per
+// thread, built to see whether a one-wavefront workgroup finds room beside k_schur_pairs, under which
+// a sweep of the four-wavefront form waits for that kernel's whole grid.  It does not: the sweep
+// still took the 150 us of the kernel beside it, and 42 instead of 20 us alone (Venice shape 2.29
+// against 2.12 ms per solve).  The default stays the four-wavefront form.
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_coarse_gj(const double* __restrict__ src, double* __restrict__ dst, int n_pad, int p) {
     __shared__ double P[kTile][kTile + 1], A[kTile][kTile + 1], B[kTile][kTile + 1], T[kTile][kTile + 1];
     const int bi = blockIdx.y, bj = blockIdx.x;
-    const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x / kTile;      // 8 rows of 32 threads
+    constexpr int kTy = kThreads / kTile, kM = kTile / kTy, kUnroll = kM > 4 ? 2 : 8;                  // rows of 32 threads; entries per thread
+    const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x / kTile;
     const bool row_p = bi == p, col_p = bj == p;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int i = ty + 8 * m;
+    for (int m = 0; m < kM; ++m) {
+        const int i = ty + kTy * m;
         if (!row_p) A[i][tx] = src[(size_t)(kTile * bi + i) * n_pad + kTile * p + tx];
         if (!col_p) B[i][tx] = src[(size_t)(kTile * p + i) * n_pad + kTile * bj + tx];
     }
@@ -161,24 +170,24 @@ __global__ __launch_bounds__(kBlock) void k_coarse_gj(const double* __restrict__
     // a step publishes the pivot row and column through LDS buffers that alternate with the
     // step's parity, so one barrier per step is enough
     __shared__ double rowbuf[2][kTile], colbuf[2][kTile];
-    double pv[4];
+    double pv[kM];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pv[m] = src[(size_t)(kTile * p + ty + 8 * m) * n_pad + kTile * p + tx];
+    for (int m = 0; m < kM; ++m) pv[m] = src[(size_t)(kTile * p + ty + kTy * m) * n_pad + kTile * p + tx];
 #pragma unroll
     for (int kk = 0; kk < kTile; ++kk) {
         const int par = kk & 1;
-        if (ty == (kk & 7)) rowbuf[par][tx] = pv[kk >> 3];
+        if (ty == kk % kTy) rowbuf[par][tx] = pv[kk / kTy];
         if (tx == kk) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) colbuf[par][ty + 8 * m] = pv[m];
+            for (int m = 0; m < kM; ++m) colbuf[par][ty + kTy * m] = pv[m];
         }
         __syncthreads();
         const double pd = rowbuf[par][kk];
         const double piv = (pd > 1e-300 && pd < 1e300) ? 1.0 / pd : 0.0;
         const double rowk = rowbuf[par][tx];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int i = ty + 8 * m;
+        for (int m = 0; m < kM; ++m) {
+            const int i = ty + kTy * m;
             const double colv = colbuf[par][i];
             double v;
             if (i == kk) v = tx == kk ? piv : rowk * piv;
@@ -187,51 +196,55 @@ __global__ __launch_bounds__(kBlock) void k_coarse_gj(const double* __restrict__
         }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) P[ty + 8 * m][tx] = pv[m];
+    for (int m = 0; m < kM; ++m) P[ty + kTy * m][tx] = pv[m];
     __syncthreads();
-    double out[4];
+    double out[kM];
     if (row_p && col_p) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) out[m] = P[ty + 8 * m][tx];
+        for (int m = 0; m < kM; ++m) out[m] = P[ty + kTy * m][tx];
     } else if (row_p) {
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
+        double s[kM];
+#pragma unroll
+            for (int m = 0; m < kM; ++m) s[m] = 0.0;
+#pragma unroll kUnroll
         for (int q = 0; q < kTile; ++q) {
             const double b = B[q][tx];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) s[m] += P[ty + 8 * m][q] * b;
+            for (int m = 0; m < kM; ++m) s[m] += P[ty + kTy * m][q] * b;
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) out[m] = s[m];
+        for (int m = 0; m < kM; ++m) out[m] = s[m];
     } else {
         {
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
+            double s[kM];
+#pragma unroll
+            for (int m = 0; m < kM; ++m) s[m] = 0.0;
+#pragma unroll kUnroll
             for (int q = 0; q < kTile; ++q) {
                 const double b = P[q][tx];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) s[m] += A[ty + 8 * m][q] * b;
+                for (int m = 0; m < kM; ++m) s[m] += A[ty + kTy * m][q] * b;
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { T[ty + 8 * m][tx] = s[m]; out[m] = -s[m]; }
+            for (int m = 0; m < kM; ++m) { T[ty + kTy * m][tx] = s[m]; out[m] = -s[m]; }
         }
         if (!col_p) {
             __syncthreads();
-            double s[4];
+            double s[kM];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) s[m] = src[(size_t)(kTile * bi + ty + 8 * m) * n_pad + kTile * bj + tx];
-#pragma unroll 8
+            for (int m = 0; m < kM; ++m) s[m] = src[(size_t)(kTile * bi + ty + kTy * m) * n_pad + kTile * bj + tx];
+#pragma unroll kUnroll
             for (int q = 0; q < kTile; ++q) {
                 const double b = B[q][tx];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) s[m] -= T[ty + 8 * m][q] * b;
+                for (int m = 0; m < kM; ++m) s[m] -= T[ty + kTy * m][q] * b;
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) out[m] = s[m];
+            for (int m = 0; m < kM; ++m) out[m] = s[m];
         }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) dst[(size_t)(kTile * bi + ty + 8 * m) * n_pad + kTile * bj + tx] = out[m];
+    for (int m = 0; m < kM; ++m) dst[(size_t)(kTile * bi + ty + kTy * m) * n_pad + kTile * bj + tx] = out[m];
 }
 
 // rc = D Z' r: one workgroup per cluster; a group of 7 threads takes every 36th camera.
@@ -386,8 +399,10 @@ const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st,
     hipLaunchKernelGGL(k_coarse_scale, dim3((unsigned)((total + kBlock - 1) / kBlock)), blk, 0, st, k, k.E[0], k.E[1]);
     int src = 1;
     const int nt = k.n_pad / kTile;
+    static const int gj_waves = [] { const char* e = getenv("SFMBA_GJ_WAVES"); return e ? atoi(e) : 4; }();     // tuning: 1 = one wavefront per tile
     for (int p = 0; p < nt; ++p) {
-        hipLaunchKernelGGL(k_coarse_gj, dim3(nt, nt), blk, 0, st, k.E[src], k.E[src ^ 1], k.n_pad, p);
+        if (gj_waves == 1) hipLaunchKernelGGL((k_coarse_gj<64>), dim3(nt, nt), dim3(64), 0, st, k.E[src], k.E[src ^ 1], k.n_pad, p);
+        else hipLaunchKernelGGL((k_coarse_gj<kBlock>), dim3(nt, nt), blk, 0, st, k.E[src], k.E[src ^ 1], k.n_pad, p);
         src ^= 1;
     }
     return k.E[src];
