@@ -115,6 +115,23 @@ def test_two_level_solve_same_cost_fewer_iterations(model):
     assert out["two-level"].pcg_iterations < 0.6 * ref.pcg_iterations
 
 
+@pytest.mark.parametrize("model", ["pinhole", "bal"])
+def test_restriction_formed_by_the_update_kernel_gives_the_same_solve(monkeypatch, model):
+    # the tuning switch that folds the restriction Z'r into k_pcg_update (per workgroup and cluster
+    # slot, put together by the prolongation): another order of additions, the same solve
+    p = _problem(model, 400, 30000, 200000, seed=7)
+    out = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("SFMBA_PCG_FUSED_RESTRICT", fused)
+        with _engine(p, model, pcg_mode=1, pcg_coarse=64, ftol=1e-9, gtol=1e-12) as eng:
+            out.append(eng.solve())
+    a, b = out
+    assert a.pcg_coarse_solves == a.iterations and b.pcg_coarse_solves == b.iterations
+    assert a.iterations == b.iterations
+    assert abs(a.pcg_iterations - b.pcg_iterations) <= 2
+    assert abs(a.final_cost - b.final_cost) <= 1e-9 * a.final_cost
+
+
 def test_two_level_solve_is_reproducible():
     p = _problem("pinhole", 300, 8000, 60000, seed=8)
     costs = []
