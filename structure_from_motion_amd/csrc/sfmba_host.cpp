@@ -1624,7 +1624,9 @@ void sfmba::finish_schur_setup(H* h, bool want_dense) {
     h->fused_coarse_wanted = false;
     // (with two or three such small clusters the correction removes a third of the iterations and
     // costs more than that: measured on chains of 21 and 47 views)
-    if (coarse >= 0 && !want_dense && (coarse > 0 || n_cam >= 256 || fused_small) && n_cam / coarse_k >= (fused_small ? 4 : 2)) {
+    int coarse_min_cams = 256;
+    if (const char* e = getenv("SFMBA_COARSE_MIN_CAMS")) coarse_min_cams = atoi(e);       // tuning
+    if (coarse >= 0 && !want_dense && (coarse > 0 || n_cam >= coarse_min_cams || fused_small) && n_cam / coarse_k >= (fused_small ? 4 : 2)) {
         const int k = coarse_k;
         const int n_cl = n_cam / k;
         std::vector<int> cl_ptr((size_t)n_cl + 1), cam_cl((size_t)n_cam);
