@@ -23,6 +23,8 @@
 // also takes over the r'z partials from k_pcg_update; the restriction Z' r is formed by k_pcg_update
 // itself (per workgroup and cluster) and by a kernel of its own only for the first residual of a solve.
 // All sums run in a fixed order, so the result is the same from run to run.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 #include "sfmba_internal.h"
@@ -56,11 +58,9 @@ __global__ __launch_bounds__(kBlock) void k_coarse_basis(Dev d, Coarse k) {
     }
     z[6 * ND + 3] = cam.t[0]; z[6 * ND + 4] = cam.t[1]; z[6 * ND + 5] = cam.t[2];
     // a camera without observations (on any rank: U is the all-ranks sum) has a zero right-hand
-    // side and must not move: it takes no part in the coarse space
-    const double* __restrict__ U = d.UG + M::NV * (size_t)c;
-    bool seen = false;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) seen = seen || U[upidx(ND, i, i)] != 0.0;
+    // side and must not move: it takes no part in the coarse space (the flag is left by the finishing
+    // pass of the damping, so that this kernel reads nothing the next linearisation rewrites)
+    const bool seen = d.cam_seen[c] != 0;
     double* out = k.Z + kVecs * ND * (size_t)c;
 #pragma unroll
     for (int i = 0; i < kVecs * ND; ++i) out[i] = seen ? z[i] : 0.0;
@@ -378,24 +378,28 @@ __global__ __launch_bounds__(kBlock) void k_coarse_prolong(Dev d, Coarse k, int 
 
 // Builds Z, E = Z'SZ and its inverse; returns the buffer that holds D^-1 E^-1 D^-1 (k.scale = D).
 // `assembled`, when given, is recorded once nothing of the problem (cameras, UG, the matrix) is
-// read any more: what follows works on the coarse matrices alone; `basis_done` as soon as the
-// cameras and UG are not (the first kernel), after which only the reduced matrix is still read.
+// read any more: what follows works on the coarse matrices alone.
 // `sum_over_ranks`, when given, is called on E once it is assembled (on `st`): with the reduced matrix
 // split over the ranks E = Z'SZ is the sum of the ranks' Z'S_k Z.
 const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled,
-                                  void (*sum_over_ranks)(void*, double*, size_t), void* ctx, hipEvent_t basis_done) {
+                                  void (*sum_over_ranks)(void*, double*, size_t), void* ctx) {
     const dim3 blk(kBlock);
+    static const bool trace = getenv("SFMBA_TRACE_COARSE_HOST") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto h0 = now();
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_basis<Bal>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
     else hipLaunchKernelGGL((k_coarse_basis<Pinhole>), dim3(cdiv(d.n_cam, kBlock)), blk, 0, st, d, k);
-    // (the cameras and U have been read: from here on only the reduced matrix is)
-    if (basis_done) (void)hipEventRecord(basis_done, st);
     const size_t total = (size_t)k.n_pad * k.n_pad;
+    const auto h1 = now();
     (void)hipMemsetAsync(k.E[0], 0, total * sizeof(double), st);
+    const auto h2 = now();
     if (d.model == MODEL_BAL) hipLaunchKernelGGL((k_coarse_assemble<Bal::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);
     else hipLaunchKernelGGL((k_coarse_assemble<Pinhole::ND>), dim3(k.n_cchunks), blk, 0, st, d, k);
     hipLaunchKernelGGL(k_coarse_collect, dim3(cdiv(k.n_cpairs * kVecs * kVecs, kBlock)), blk, 0, st, k, k.E[0]);
     if (sum_over_ranks) sum_over_ranks(ctx, k.E[0], total);
+    const auto h3 = now();
     if (assembled) (void)hipEventRecord(assembled, st);
+    const auto h4 = now();
     hipLaunchKernelGGL(k_coarse_scale, dim3((unsigned)((total + kBlock - 1) / kBlock)), blk, 0, st, k, k.E[0], k.E[1]);
     int src = 1;
     const int nt = k.n_pad / kTile;
@@ -404,6 +408,11 @@ const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st,
         if (gj_waves == 1) hipLaunchKernelGGL((k_coarse_gj<64>), dim3(nt, nt), dim3(64), 0, st, k.E[src], k.E[src ^ 1], k.n_pad, p);
         else hipLaunchKernelGGL((k_coarse_gj<kBlock>), dim3(nt, nt), blk, 0, st, k.E[src], k.E[src ^ 1], k.n_pad, p);
         src ^= 1;
+    }
+    if (trace) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "coarse set-up, host time: basis %.1f, memset %.1f, assemble + collect %.1f, event %.1f, scale + %d sweeps %.1f us\n",
+                us(h0, h1), us(h1, h2), us(h2, h3), us(h3, h4), nt, us(h4, now()));
     }
     return k.E[src];
 }

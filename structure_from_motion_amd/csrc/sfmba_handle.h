@@ -146,6 +146,7 @@ struct HandleData {
     int n_wtiles = 0;
     DBuf<double> pm_rv, cm_sx, cm_sy, cm_siz;
     DBuf<double> V, gp, Vinv, chunk_part, UG, T, Minv, rhs;
+    DBuf<unsigned char> cam_seen;          // [n_cam] cameras with observations (on any rank), from the last finishing pass
     DBuf<double4> s, s0;
     DBuf<double> px, pr, pz, pp[2], pq, qS;
     DBuf<PcgState> pcg;
@@ -195,7 +196,7 @@ struct HandleData {
     double solve_rtol = 0.0;          // PCG tolerance of the sfmba_solve in progress (0 outside one)
     double model_gain_floor = -1.0;   // inside a solve: a PCG iteration that lowers the model by less than this is not worth its time (< 0: rule off)
     DBuf<int> wg_cl;
-    hipEvent_t ev_c_basis = nullptr, ev_c_assembled = nullptr, ev_c_done = nullptr;
+    hipEvent_t ev_c_assembled = nullptr, ev_c_done = nullptr;
     // dense Cholesky solver
     bool use_dense = false;      // dense Cholesky asked for
     bool dense_allowed = false;  // small enough for the dense fallback
@@ -232,7 +233,6 @@ struct HandleData {
         for (auto e : pcg_ev) if (e) (void)hipEventDestroy(e);
         if (pcg_host) (void)hipHostFree(pcg_host);
         if (scalars_host) (void)hipHostFree(scalars_host);
-        if (ev_c_basis) (void)hipEventDestroy(ev_c_basis);
         if (ev_c_assembled) (void)hipEventDestroy(ev_c_assembled);
         if (ev_c_done) (void)hipEventDestroy(ev_c_done);
         if (comm && comm_destroy) comm_destroy(comm);

@@ -197,7 +197,7 @@ void refresh_dev(H* h) {
     d.n_wtiles = h->n_wtiles; d.wtile_beg = h->wtile_beg.p;
     d.cm_sx = h->cm_sx.p; d.cm_sy = h->cm_sy.p; d.cm_siz = h->cm_siz.p;
     d.V = h->V.p; d.gp = h->gp.p; d.Vinv = h->Vinv.p; d.s = h->s.p; d.s0 = h->s0.p;
-    d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p;
+    d.chunk_part = h->chunk_part.p; d.UG = h->UG.p; d.T = h->T.p; d.Minv = h->Minv.p; d.rhs = h->rhs.p; d.cam_seen = h->cam_seen.p;
     d.px = h->px.p; d.pr = h->pr.p; d.pz = h->pz.p; d.pp[0] = h->pp[0].p; d.pp[1] = h->pp[1].p; d.pq = h->pq.p; d.qS = h->qS.p;
     d.pcg = h->pcg.p; d.pcg_mirror = h->pcg_host; d.dot_part = h->dot_part.p; d.scal_part = h->scal_part.p; d.scalars = h->scalars.p;
     // (with a communicator the slots are summed over the ranks on the device and then copied)
@@ -317,9 +317,10 @@ void reduce_scalars(H* h, int first, int count) {
 // them only with those of the trial step that follows: they are finished by that step's launch
 // (phase_trial) instead of two small launches of their own.
 // The coarse operator of the single-launch PCG is set up on copy_stream beside the kernels of the
-// next linearisation.  It reads the cameras and UG up to the event ev_c_basis and the reduced matrix
-// up to ev_c_assembled: whatever overwrites those on the main stream waits for the event first, and
-// the PCG launch that uses the operator waits for ev_c_done.
+// next linearisation.  It reads the reduced matrix up to the event ev_c_assembled: the finishing
+// passes that overwrite it on the main stream wait for the event first, and the PCG launch that uses
+// the operator waits for ev_c_done.  (Its other inputs are not rewritten while it runs: the cameras of
+// the current point - a trial step goes into the other buffer - and the flags of the observed cameras.)
 // (Giving the second stream the device's highest priority was measured and changes nothing: a sweep
 // of the coarse operator's chain that is launched while k_schur_pairs runs - one-wavefront workgroups
 // at three per SIMD, refilled one at a time - finds its four wavefront slots on one compute unit only
@@ -327,25 +328,20 @@ void reduce_scalars(H* h, int first, int count) {
 void ensure_copy_stream(H* h) {
     if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
 }
-// Two waits: what rewrites U or the cameras (the camera-major pass of a linearisation) waits for the
-// set-up's first kernel only; what rewrites the reduced matrix (the finishing passes of phase_damp)
-// for its assembly, which at 13 682 cameras takes as long as the point-major pass beside it.
-void wait_coarse_basis(H* h) {
-    if (h->fused_coarse_ready) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_basis, 0));
-}
+// What rewrites the reduced matrix (the finishing passes of phase_damp) waits for the set-up's
+// assembly, which at 13 682 cameras takes as long as the point-major pass beside it.
 void wait_coarse_matrix(H* h) {
     if (h->fused_coarse_ready) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_c_assembled, 0));
 }
 void start_fused_coarse(H* h) {
     if (!h->ev_c_done) {
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_c_basis, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_c_assembled, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_c_done, hipEventDisableTiming));
     }
     ensure_copy_stream(h);
     // (the caller has waited for the main stream: the matrix of the solve just finished is in
     // place and no single-launch solve that could still read the last operator is running)
-    h->fused_einv = launch_coarse_setup(h->dev, h->coarse, h->copy_stream, h->ev_c_assembled, nullptr, nullptr, h->ev_c_basis);
+    h->fused_einv = launch_coarse_setup(h->dev, h->coarse, h->copy_stream, h->ev_c_assembled);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_c_done, h->copy_stream));
     h->fused_coarse_ready = true;
@@ -368,11 +364,6 @@ void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false, bool def
     refresh_dev(h);
     defer = defer && !h->has_comm();
     launch_lin_pm(h->dev, !h->explicit_schur, lambda, h->stream, grad_only, /*keep_v=*/false, defer);
-    // (the set-up is queued on its stream after the point-major pass is on its way: the host time
-    // of its launches falls into that kernel's run)
-    if (h->fused_coarse_wanted && !grad_only) start_fused_coarse(h);
-    h->fused_coarse_wanted = false;
-    wait_coarse_basis(h);
     h->lin_owed = defer;
     h->damped_lambda = lambda > 0.0 && !grad_only ? lambda : -1.0;
     h->have_v = !grad_only && !(lambda > 0.0);
@@ -396,6 +387,15 @@ void phase_linearize(H* h, double lambda = 0.0, bool grad_only = false, bool def
         allreduce(h, h->UG.p, (size_t)h->n_cam * h->cv + nr);
     }
     if (!defer) launch_gmax_cam(h->dev, h->stream);
+    // The coarse operator's set-up is queued on its stream once both passes of the linearisation are
+    // on their way.  It reads nothing a linearisation writes: the cameras of the point it belongs to,
+    // the reduced matrix, and the flags of the cameras that have observations, which the last
+    // finishing pass left.  (Its launches take the host 45 us at 1 778 cameras and 70 us at 13 682 -
+    // SFMBA_TRACE_COARSE_HOST=1 prints them - and several times that under the kernel tracer, whose
+    // time lines therefore show the main stream waiting for the host around this point; without the
+    // tracer the order of these calls makes no measurable difference.)
+    if (h->fused_coarse_wanted && !grad_only) start_fused_coarse(h);
+    h->fused_coarse_wanted = false;
     h->linearized = false;
 }
 
@@ -411,7 +411,6 @@ void damp_points(H* h, double lambda) {
 // mode also the whole block-sparse reduced matrix S.
 void phase_damp(H* h, double lambda) {
     if (h->fused_coarse_wanted) { start_fused_coarse(h); h->fused_coarse_wanted = false; }   // (after a rejected step)
-    wait_coarse_basis(h);
     if (h->explicit_schur) {
         // per camera, behind the blocks: T_c = sum W Vinv W' (its own observations: the diagonal
         // block's share) and sum W Vinv g_p (the point part of the right-hand side)
@@ -1942,6 +1941,7 @@ void alloc_work_buffers(H* h) {
     h->UG.alloc((size_t)n_cam * cv + (size_t)std::max(1, h->opt.nranks)); h->T.alloc((size_t)n_cam * cv);
     h->UG.zero(h->stream);
     h->Minv.alloc((size_t)n_cam * cd * cd); h->rhs.alloc((size_t)n_cam * cd);
+    h->cam_seen.alloc((size_t)n_cam);
     for (DBuf<double>* b : {&h->px, &h->pr, &h->pz, &h->pp[0], &h->pp[1], &h->pq, &h->qS}) b->alloc((size_t)n_cam * cd);
     h->nb_bsr = bsr_blocks_host((int)n_cam, h->model);
     {

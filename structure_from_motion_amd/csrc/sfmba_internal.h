@@ -142,6 +142,7 @@ struct Dev {
     double* px; double* pr; double* pz; double* pq; double* qS;
     double* pp[2];      // search direction, double-buffered by iteration parity
     PcgState* pcg;      // [2], double-buffered by iteration parity
+    unsigned char* cam_seen; // [n_cam] 1 where the camera has observations on any rank (U_cc not zero), written by the finishing pass of every damping
     PcgState* pcg_mirror;   // pinned host memory: the launch-per-iteration solver writes the state of every iteration there too
     double* dot_part;   // block partials of p'q at [0, dot_off), of r'z at [dot_off, ...)
     int dot_off;        // offset of the r'z partials inside dot_part (p'q partials start at 0)
@@ -261,8 +262,7 @@ void launch_bsr_spmv(const Dev& d, const double* x, double* y, hipStream_t st);
 void launch_bsr_to_dense(const Dev& d, double* A, int n, hipStream_t st);
 // sfmba_coarse.hip
 const double* launch_coarse_setup(const Dev& d, const Coarse& k, hipStream_t st, hipEvent_t assembled = nullptr,
-                                  void (*sum_over_ranks)(void*, double*, size_t) = nullptr, void* ctx = nullptr,
-                                  hipEvent_t basis_done = nullptr);    // returns the buffer holding the inverse
+                                  void (*sum_over_ranks)(void*, double*, size_t) = nullptr, void* ctx = nullptr);    // returns the buffer holding the inverse
 // from_parts: the restriction is taken from k.rpart (left by launch_pcg_update) instead of being formed here
 void launch_coarse_apply(const Dev& d, const Coarse& k, int state, hipStream_t st, bool from_parts = false);  // pz += Z E^-1 Z' pr, r'z partials
 // sfmba_triangulate.hip (projection matrices are host arrays of 12 doubles, row-major 3x4)

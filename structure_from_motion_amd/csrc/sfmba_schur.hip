@@ -216,6 +216,12 @@ __global__ __launch_bounds__(64) void k_finish_diag(Dev d, double lambda, const 
             S[i][j] = uv - T[upidx(ND, a, b)] - B[ND * i + j];
             Li[i][j] = 0.0;
         }
+    {
+        bool seen = false;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) seen = seen || U[upidx(ND, i, i)] != 0.0;
+        d.cam_seen[c] = seen ? 1 : 0;
+    }
     double* So = d.Sfull + NN * (size_t)d.bsr_diag[c];
     double dg[ND];
 #pragma unroll
