@@ -2195,8 +2195,10 @@ int sfmba_reset_params(sfmba_handle* h) {
         h->cur = 0;
         HIP_TRY(hipMemcpyAsync(h->cams[0].p, h->cams0.p, h->cams0.n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
         if (h->X0.n) {
+            // (the other buffer needs no copy: a trial step writes every point that has observations
+            // before anything reads it, and the points without observations have held their loaded
+            // values in both buffers since the problem was set)
             HIP_TRY(hipMemcpyAsync(h->X[0].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->X[1].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
         }
         h->linearized = false;
         refresh_dev(h);
