@@ -211,6 +211,7 @@ struct HandleData {
     DBuf<double> czhat;           // F^-T Z of every camera for the single-launch PCG with 9 x 9 blocks
     DBuf<double> dsum;            // its per-camera collective: diagonal blocks | T_c and right-hand-side part
     int cur = 0;                           // index of the current parameter buffers
+    bool at_start = false;                 // the current parameters are the loaded ones (cams0, X0: read only), a trial step goes into buffer 0
     Dev dev{};
 
     // communication

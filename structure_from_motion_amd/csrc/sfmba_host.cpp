@@ -191,8 +191,9 @@ void refresh_dev(H* h) {
     d.pt_ptr = h->pt_ptr.p; d.pm_cam = h->pm_cam.p; d.pm_pt = h->pm_pt.p; d.pm_orig = h->pm_orig.p;
     d.pm_uv = h->pm_uv.p; d.cm_pt = h->cm_pt.p; d.cm_uv = h->cm_uv.p;
     d.chunk_cam = h->chunk_cam.p; d.chunk_beg = h->chunk_beg.p; d.cam_chunk_ptr = h->cam_chunk_ptr.p;
-    d.cams = h->cams[h->cur].p; d.X = h->X[h->cur].p;
-    d.cams_trial = h->cams[h->cur ^ 1].p; d.X_trial = h->X[h->cur ^ 1].p;
+    // (after sfmba_reset_params the current point is the loaded one, which is kept read-only: no copy)
+    d.cams = h->at_start ? h->cams0.p : h->cams[h->cur].p; d.X = h->at_start ? h->X0.p : h->X[h->cur].p;
+    d.cams_trial = h->cams[h->at_start ? 0 : h->cur ^ 1].p; d.X_trial = h->X[h->at_start ? 0 : h->cur ^ 1].p;
     d.pm_seed = h->pm_seed.p; d.pm_rv = h->pm_rv.p;
     d.n_wtiles = h->n_wtiles; d.wtile_beg = h->wtile_beg.p;
     d.cm_sx = h->cm_sx.p; d.cm_sy = h->cm_sy.p; d.cm_siz = h->cm_siz.p;
@@ -1052,7 +1053,7 @@ void do_solve(H* h, sfmba_stats* out) {
             emit(h, "  lm %3d cost %.9e -> %.9e rho %+.3f lambda %.2e |dx| %.2e pcg %d%s\n", it, cost, cost_new, rho, lambda, step_norm,
                  st.pcg_iterations - pcg_before, h->coarse_solves > coarse_before ? " (two-level)" : "");
         if (rho > 1e-3) {
-            h->cur ^= 1;
+            if (h->at_start) { h->at_start = false; h->cur = 0; } else h->cur ^= 1;
             ++accepted;
             held_back_steps = nu > 2.0 ? held_back_steps + 1 : 0;
             {
@@ -1206,6 +1207,7 @@ void do_set_params(H* h, const double* camera_params, const double* points_3d, b
     const size_t np = (size_t)h->n_pts;
     if (!points_on_device) h->in_pts.alloc(3 * np);
     h->cur = 0;
+    h->at_start = false;
     h->cams[0].upload(cams, h->stream);
     h->cams[1].alloc(cams.size());
     h->X[0].alloc(np); h->X[1].alloc(np); h->X0.alloc(np);
@@ -2192,14 +2194,12 @@ int sfmba_set_params(sfmba_handle* h, const double* camera_params, const double*
 int sfmba_reset_params(sfmba_handle* h) {
     return guarded(h, [&] {
         need_problem(h, "sfmba_reset_params");
+        // No copy: the loaded parameters (cams0, X0) become the current point as they are; they are
+        // never written - the first trial step goes into buffer 0, which takes over when it is
+        // accepted.  (The points without observations have held their loaded values in both buffers
+        // since the problem was set, and no step rewrites them.)
         h->cur = 0;
-        HIP_TRY(hipMemcpyAsync(h->cams[0].p, h->cams0.p, h->cams0.n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-        if (h->X0.n) {
-            // (the other buffer needs no copy: a trial step writes every point that has observations
-            // before anything reads it, and the points without observations have held their loaded
-            // values in both buffers since the problem was set)
-            HIP_TRY(hipMemcpyAsync(h->X[0].p, h->X0.p, h->X0.n * sizeof(double4), hipMemcpyDeviceToDevice, h->stream));
-        }
+        h->at_start = true;
         h->linearized = false;
         refresh_dev(h);
     });
@@ -2247,9 +2247,10 @@ int sfmba_solve(sfmba_handle* h, sfmba_stats* stats) {
 int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) {
     return guarded(h, [&] {
         need_problem(h, "sfmba_get_params");
+        refresh_dev(h);
         if (camera_params && h->model == MODEL_BAL) {
             std::vector<double> rec((size_t)h->n_cam * 16);
-            HIP_TRY(hipMemcpyAsync(rec.data(), h->cams[h->cur].p, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(rec.data(), h->dev.cams, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             for (int64_t c = 0; c < h->n_cam; ++c) {
                 const double* r = rec.data() + 16 * c;
@@ -2258,7 +2259,7 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
                 for (int i = 0; i < 6; ++i) o[3 + i] = r[9 + i];
             }
         } else if (camera_params) {
-            HIP_TRY(hipMemcpyAsync(camera_params, h->cams[h->cur].p, (size_t)h->n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(camera_params, h->dev.cams, (size_t)h->n_cam * 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         }
         if (points_3d) {
             // back into the caller's numbering on the device; with several ranks every rank returns
@@ -2267,7 +2268,7 @@ int sfmba_get_params(sfmba_handle* h, double* camera_params, double* points_3d) 
             if (h->tmp_a.n < full) h->tmp_a.alloc(full);
             if (h->has_comm()) HIP_TRY(hipMemsetAsync(h->tmp_a.p, 0, full * sizeof(double), h->stream));
             double* dst = h->tmp_a.p + (h->has_comm() ? 3 * (size_t)h->pt_lo : 0);
-            if (h->n_pts) launch_points_out(h->X[h->cur].p, h->new2old_dev.p, h->n_pts, dst, h->stream);
+            if (h->n_pts) launch_points_out(h->dev.X, h->new2old_dev.p, h->n_pts, dst, h->stream);
             if (h->has_comm()) {
                 allreduce(h, h->tmp_a.p, full);
                 HIP_TRY(hipMemcpyAsync(points_3d, h->tmp_a.p, full * sizeof(double), hipMemcpyDeviceToHost, h->stream));

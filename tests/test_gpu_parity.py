@@ -366,6 +366,33 @@ def test_inputs_are_not_modified_and_solve_is_deterministic():
     assert costs[0] == costs[1]          # fixed-order reductions: bitwise reproducible
 
 
+def test_reset_params_restores_the_loaded_point_on_the_same_handle():
+    # reset_params copies nothing: the loaded parameters become the current point again as they are
+    # (read-only), the first trial step goes into a buffer of its own - also for a point without
+    # observations, which no step ever writes
+    g = load_golden("tiny_4_50_150")
+    pts = np.vstack([g["points_3d"], [[7.0, -3.0, 2.0]]])                    # point 50: no observations
+    for solver in SOLVERS.values():
+        with Engine(**solver) as eng:
+            eng.set_problem(g["camera_params"], pts, g["camera_indices"], g["point_indices"], g["points_2d"], g["K"])
+            poses0, X0 = eng.get_params()
+            r0 = eng.residuals()
+            runs = []
+            for _ in range(3):
+                st = eng.solve()
+                poses1, X1 = eng.get_params()
+                runs.append((st.final_cost, st.iterations, poses1.copy(), X1.copy()))
+                eng.reset_params()
+                poses, X = eng.get_params()
+                assert np.array_equal(poses, poses0) and np.array_equal(X, X0)
+                assert np.array_equal(eng.residuals(), r0)
+            assert not np.array_equal(runs[0][3][:50], X0[:50])                 # the solves did move the points
+            for cost, its, poses1, X1 in runs[1:]:
+                assert cost == runs[0][0] and its == runs[0][1]
+                assert np.array_equal(poses1, runs[0][2]) and np.array_equal(X1, runs[0][3])
+            assert np.array_equal(runs[0][3][50], pts[50])
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_index_out_of_range_raises_index_error():
     g = load_golden("tiny_4_50_150")
