@@ -432,6 +432,11 @@ def main():
             "setup_seconds_device_inputs": setup_dev_s,
             "optimize_seconds_end_to_end": setup_warm_s + elapsed / args.steps,
             "pcg_single_fallbacks_per_solve": sum(s.pcg_single_fallbacks for s in stats) / args.steps,
+            # kernel time of the linear solves of the event-bracketed solve per PCG iteration it took:
+            # the product launches (or the single launches) plus the vector and coarse-space kernels
+            "pcg_us_per_iteration": (1e3 * (families["bsr"]["total_ms"] + families["pcg_vec"]["total_ms"]
+                                            + families["spmv_pm"]["total_ms"] + families["spmv_cm"]["total_ms"])
+                                     / ps.pcg_iterations) if ps.pcg_iterations else None,
             "roofline": roof, "kernels": families,
             "kernels_note": "per-family totals of one extra solve with HIP events around every launch: launches are "
                             "serialised there (the coarse set-up of the second stream no longer overlaps), so their sum "
